@@ -1,0 +1,178 @@
+/*
+ * exaspim_affinity.h -- C ABI of the MI355X (gfx950) sliding-window 3D-UNet
+ * affinity-inference path.
+ *
+ * The reference (AllenNeuralDynamics/aind-exaspim-neuron-segmentation) has no
+ * FFI on this path: it is plain Python over torch. The entry points below are
+ * what a binding for that path needs; each one names the reference code it
+ * replaces (paths relative to src/aind_exaspim_neuron_segmentation/). The
+ * reference-side ctypes stub a maintainer would add is in INTEGRATION.md.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch types.
+ *  - Every function that can fail returns int: 0 = ok, negative = error
+ *    (EXASPIM_E_*); exaspim_last_error() returns a thread-local message.
+ *  - "dev" pointers are HIP device pointers owned by the caller (e.g.
+ *    torch.Tensor.data_ptr()); the library never allocates or frees device
+ *    memory and never synchronises the device. Kernels are enqueued on the
+ *    caller's HIP stream ("stream", a hipStream_t passed as void*; NULL = the
+ *    default stream).
+ *  - Volumes are C-ordered (z, y, x). Activations handed across the ABI are
+ *    NCDHW float32, like the reference's tensors; the channels-last 16-byte
+ *    grouped layout used between kernels is internal to the workspace.
+ */
+#ifndef EXASPIM_AFFINITY_H
+#define EXASPIM_AFFINITY_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EXASPIM_ABI_VERSION 1
+
+/* error codes */
+#define EXASPIM_OK 0
+#define EXASPIM_E_INVALID (-1)   /* bad argument (shape, dtype, NULL)        */
+#define EXASPIM_E_HIP (-2)       /* HIP runtime error (message has details)  */
+#define EXASPIM_E_WORKSPACE (-3) /* workspace too small                      */
+#define EXASPIM_E_NODEVICE (-4)  /* no usable gfx950 device                  */
+
+/* compute dtype of the network (activations and weights between kernels;
+ * accumulation is always float32) */
+#define EXASPIM_DT_F32 0  /* exact f32 MFMA (v_mfma_f32_32x32x2_f32)        */
+#define EXASPIM_DT_BF16 1 /* bf16 storage, v_mfma_f32_32x32x16_bf16         */
+#define EXASPIM_DT_F16 2  /* f16 storage,  v_mfma_f32_32x32x16_f16          */
+
+/* voxel dtype of an input volume */
+#define EXASPIM_VOX_U8 0
+#define EXASPIM_VOX_U16 1
+#define EXASPIM_VOX_I16 2
+#define EXASPIM_VOX_F32 3
+
+typedef struct exaspim_unet exaspim_unet; /* opaque engine handle */
+
+/* 3-D block of a (possibly larger, possibly sharded) volume. "dims" is the
+ * shape of the local array, "origin" the global coordinate of its first
+ * voxel, "global" the shape of the whole volume. Single-device callers pass
+ * origin = 0 and global = dims. */
+typedef struct exaspim_block {
+    int32_t dims[3];
+    int32_t origin[3];
+    int32_t global[3];
+} exaspim_block;
+
+/* sliding-window geometry: predict()'s patch_shape / overlap / trim
+ * (inference.py:36-38) */
+typedef struct exaspim_window {
+    int32_t patch[3];
+    int32_t overlap[3];
+    int32_t trim;
+} exaspim_window;
+
+int exaspim_abi_version(void);
+const char* exaspim_last_error(void);
+
+/* ---- model: replaces load_model() / UNet3D (inference.py:400-424,
+ *      machine_learning/unet3d.py:16-336; trilinear=True only) ------------ */
+
+/* Number of float32 values in the canonical parameter vector for a UNet3D
+ * with level widths channels[0..4] (unet3d.py:56) and "out_channels" head
+ * outputs: the state_dict tensors in state_dict order, "num_batches_tracked"
+ * skipped, i.e. per conv: weight(Cout,Cin,3,3,3), bias, bn.weight, bn.bias,
+ * bn.running_mean, bn.running_var; finally outc.conv.weight, outc.conv.bias. */
+size_t exaspim_unet_param_count(const int32_t channels[5], int32_t out_channels);
+
+/* Size of the packed device image of the weights for a compute dtype. */
+size_t exaspim_unet_packed_bytes(const int32_t channels[5], int32_t out_channels,
+                                 int32_t dtype);
+
+/* Host-only: folds eval-mode BatchNorm (eps 1e-5, unet3d.py:144,147) into the
+ * preceding convolution (in float64), converts to "dtype" and lays the result
+ * out in MFMA fragment order. "packed_host" receives packed_bytes bytes which
+ * the caller uploads to the device unchanged. */
+int exaspim_unet_pack_weights(const int32_t channels[5], int32_t out_channels,
+                              int32_t dtype, const float* params, size_t n_params,
+                              void* packed_host, size_t packed_bytes);
+
+/* Binds a packed weight image that already lives on device "device". The
+ * image must outlive the handle. */
+int exaspim_unet_create(const int32_t channels[5], int32_t out_channels,
+                        int32_t dtype, int32_t device, const void* packed_dev,
+                        size_t packed_bytes, exaspim_unet** out);
+void exaspim_unet_destroy(exaspim_unet* h);
+
+/* Scratch bytes exaspim_unet_forward needs for a batch of n patches of
+ * d x h x w voxels (each a multiple of 16, the constraint the reference's
+ * Up.forward imposes, unet3d.py:281-288). */
+size_t exaspim_unet_workspace_bytes(const exaspim_unet* h, int32_t n, int32_t d,
+                                    int32_t hgt, int32_t w);
+
+/* UNet3D.forward (unet3d.py:77-105): x_dev is float32 (n,1,d,h,w); out_dev
+ * receives float32 (n,out_channels,d,h,w) logits, or sigmoid(logits) when
+ * apply_sigmoid != 0 (inference.py:158). */
+int exaspim_unet_forward(exaspim_unet* h, const float* x_dev, float* out_dev,
+                         int32_t n, int32_t d, int32_t hgt, int32_t w,
+                         int32_t apply_sigmoid, void* workspace_dev,
+                         size_t workspace_bytes, void* stream);
+
+/* ---- pre-processing: replaces np.minimum + img_util.normalize +
+ *      _get_batch_inputs (inference.py:79-80,166-192;
+ *      utils/img_util.py:362-379,405-428,504-533) ------------------------- */
+
+/* Adds the 65536-bin histogram of min(voxel, clip) (clip applied iff
+ * has_clip) over "n" voxels into hist_dev (uint64[65536], caller-zeroed).
+ * 8/16-bit integer voxels are binned by value (I16: value + 32768). F32
+ * voxels are binned by an order-preserving 32-bit key: pass 0 bins the key's
+ * high 16 bits; pass 1 bins the low 16 bits of keys whose high half equals
+ * "prefix". Order statistics, and from them numpy's linear-interpolated
+ * percentiles (img_util.py:526), follow exactly from these counts. */
+int exaspim_histogram(const void* vol_dev, int32_t vox_dtype, size_t n,
+                      double clip, int32_t has_clip, int32_t pass,
+                      uint32_t prefix, uint64_t* hist_dev, void* stream);
+
+/* Builds a batch of network inputs: for patch i with global start
+ * starts_dev[3*i..3*i+2] (int32 z,y,x), out[i] (float32 patch[0] x patch[1] x
+ * patch[2]) = float32(clip01((min(v, clip) - mn) / denom)) evaluated in
+ * float64, with v taken from the volume block and the part of the patch that
+ * sticks out of the GLOBAL volume filled by numpy 'reflect' padding of the
+ * in-volume part (img_util.py:378-379). denom = mx - mn + 1e-8. */
+int exaspim_gather_patches(const void* vol_dev, int32_t vox_dtype,
+                           const exaspim_block* blk, const int32_t* starts_dev,
+                           int32_t n, const int32_t patch[3], double clip,
+                           int32_t has_clip, double mn, double denom,
+                           float* out_dev, void* stream);
+
+/* ---- post-processing: replaces the stitch loop and the final divide
+ *      (inference.py:99-116,120-125) -------------------------------------- */
+
+/* accum[c, s:e] += pred[i, c, trim:trim+(e-s)] for every patch i of the batch
+ * in batch order, s = start + trim, e = min(s + patch - 2*trim, global dim),
+ * restricted to the accumulator block. pred_dev is float32
+ * (n, channels, patch) (the sigmoid output of exaspim_unet_forward);
+ * accum_dev is float32 (channels, blk->dims). Deterministic: each voxel is
+ * summed by one thread in patch order, so repeated runs are bit-identical. */
+int exaspim_stitch_accumulate(const float* pred_dev, const int32_t* starts_dev,
+                              int32_t n, int32_t channels,
+                              const exaspim_window* win, float* accum_dev,
+                              const exaspim_block* blk, void* stream);
+
+/* accum[c, v] /= (number of patches whose trimmed output covers v) where that
+ * number is non-zero (it is a product of three per-axis counts fixed by the
+ * geometry alone); uncovered voxels keep 0. */
+int exaspim_stitch_finalize(float* accum_dev, int32_t channels,
+                            const exaspim_window* win, const exaspim_block* blk,
+                            void* stream);
+
+/* ---- synthetic input for benchmarks and tests --------------------------- */
+
+/* vol[z,y,x] = splitmix64(seed + global linear index) % 2000 as uint16. */
+int exaspim_synth_volume_u16(uint16_t* vol_dev, const exaspim_block* blk,
+                             uint64_t seed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EXASPIM_AFFINITY_H */

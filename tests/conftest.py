@@ -1,0 +1,29 @@
+"""Shared pytest configuration: markers, import path and fixture helpers."""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line(
+        "markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)"
+    )
+
+
+def load_golden(name):
+    """Loads a committed golden fixture (plain arrays, no pickles)."""
+    return np.load(os.path.join(GOLDEN_DIR, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden

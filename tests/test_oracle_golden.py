@@ -1,0 +1,161 @@
+"""
+Pins the CPU oracle (oracle/reference_path.py) against golden vectors that
+tests/golden/make_golden.py produced by running the imported reference.
+CPU-only; the oracle is the checker for every GPU parity test.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from aind_exaspim_neuron_segmentation_amd.utils import synthetic
+from oracle import reference_path as oracle
+
+
+def test_patch_start_tables(golden):
+    g = golden("g1_patch_starts.npz")
+    for i in range(int(g["n_cases"])):
+        vol = tuple(int(v) for v in g[f"case{i}_vol"])
+        ps = tuple(int(v) for v in g[f"case{i}_patch"])
+        ov = tuple(int(v) for v in g[f"case{i}_overlap"])
+        shape5 = (1, 1) + vol
+        assert oracle.count_patches(shape5, ps, ov) == int(g[f"case{i}_count"])
+        starts = np.array(
+            list(oracle.generate_patch_starts(shape5, ps, ov)), dtype=np.int64
+        ).reshape(-1, 3)
+        if vol == (512, 512, 512):
+            starts = starts[[0, 1, 7, 8, 63, 64, 510, 511]]
+        np.testing.assert_array_equal(starts, g[f"case{i}_starts"])
+
+
+def test_patch_helpers_assert_on_non_5d():
+    with pytest.raises(AssertionError):
+        oracle.count_patches((96, 96, 96), (96,) * 3, (32,) * 3)
+    with pytest.raises(AssertionError):
+        list(oracle.generate_patch_starts((1, 96, 96, 96), (96,) * 3, (32,) * 3))
+
+
+def _normalize_cases():
+    vol = synthetic.synth_volume((40, 48, 56), seed=3)
+    return {
+        "u16_clip1000": np.minimum(vol, 1000),
+        "u16_noclip": vol,
+        "u16_sparse": np.where(vol > 1990, vol * 20, vol // 50).astype(np.uint16),
+        "f32": (vol.astype(np.float32) * 0.37 - 50.0),
+        "u8": (vol % 251).astype(np.uint8),
+        "i16": (vol.astype(np.int32) - 1000).astype(np.int16),
+        "const": np.full((8, 8, 8), 7, dtype=np.uint16),
+    }
+
+
+def test_normalize_known_answers(golden):
+    g = golden("g2_normalize.npz")
+    for name, arr in _normalize_cases().items():
+        for pct_name, pct in (("default", (1, 99.9)), ("alt", (0.5, 75.25))):
+            res = oracle.normalize(arr, percentiles=pct)
+            assert res.dtype == np.float64
+            np.testing.assert_array_equal(
+                res[::3, ::5, ::7], g[f"{name}_{pct_name}_out"]
+            )
+
+
+def test_reflect_padding_and_slices(golden):
+    g = golden("g2b_padding.npz")
+    for i in range(int(g["n_cases"])):
+        patch = g[f"case{i}_in"]
+        ps = tuple(int(v) for v in g[f"case{i}_patch_shape"])
+        want = g[f"case{i}_out"]
+        np.testing.assert_array_equal(oracle.add_padding(patch, ps), want)
+        # closed form used by the HIP gather kernel
+        idx = [
+            [oracle.reflect_index(j, n) for j in range(p)]
+            for p, n in zip(ps, patch.shape)
+        ]
+        np.testing.assert_array_equal(patch[np.ix_(*idx)], want)
+    sl = oracle.get_patch_slices((64, 0, 128), (96, 96, 96), (130, 50, 224))
+    np.testing.assert_array_equal(
+        np.array([[s.start, s.stop] for s in sl]), g["slices"]
+    )
+
+
+def test_tiny_model_full_pipeline(golden):
+    g = golden("g3_tiny_predict.npz")
+    vol = synthetic.synth_volume((56, 40, 48), seed=7)
+    kw = dict(batch_size=3, patch_shape=(32, 32, 32), overlap=(8, 8, 8), trim=4)
+    model = oracle.OracleModel(synthetic.synth_state_dict(3, 0.125, seed=2))
+    pred = oracle.predict(vol, model, **kw)
+    assert pred.dtype == np.float32 and pred.shape == (3, 56, 40, 48)
+    np.testing.assert_allclose(pred, g["pred"], rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(pred == 0, g["pred"] == 0)
+
+    model1 = oracle.OracleModel(synthetic.synth_state_dict(1, 0.125, seed=2))
+    pred1 = oracle.predict(vol, model1, affinity_mode=False, **kw)
+    assert pred1.shape == (56, 40, 48)
+    np.testing.assert_allclose(pred1, g["pred_fg"], rtol=0, atol=2e-6)
+
+    volf = (vol.astype(np.float32) * 0.5)[None, None]
+    kw0 = dict(kw, trim=0, brightness_clip=400, normalization_percentiles=(5, 95))
+    pred0 = oracle.predict(volf, model, **kw0)
+    np.testing.assert_allclose(
+        pred0[:, ::2, ::2, ::2], g["pred_f32_notrim"], rtol=0, atol=2e-6
+    )
+
+
+def test_full_width_single_patch(golden):
+    g = golden("g4_single_patch.npz")
+    sd = synthetic.synth_state_dict(3, 1, seed=1)
+    vol = synthetic.synth_volume((96, 96, 96), seed=0)
+    img = oracle.normalize(np.minimum(vol, 1000))
+    x = torch.tensor(img[None, None].astype(np.float32))
+    logits, feats = oracle.unet_forward(x, oracle.OracleModel(sd).sd, True)
+    np.testing.assert_allclose(
+        logits[0, :, ::8, ::8, ::8].numpy(), g["logits_sub"], rtol=0, atol=5e-6
+    )
+    np.testing.assert_allclose(
+        logits[0, :, 40:44, 17:21, :].numpy(), g["logits_slab"], rtol=0, atol=5e-6
+    )
+    names = dict(inc="x1", down1="x2", down2="x3", down3="x4", down4="x5",
+                 up1="y1", up2="y2", up3="y3", up4="y4")
+    for ref_name, key in names.items():
+        f = feats[key]
+        step = max(1, f.shape[2] // 6)
+        np.testing.assert_allclose(
+            f[0, ::4, ::step, ::step, ::step].numpy(), g[f"{ref_name}_sub"],
+            rtol=0, atol=5e-6,
+        )
+        stats = np.array([f.double().mean().item(), f.double().abs().mean().item(),
+                          f.min().item(), f.max().item()])
+        np.testing.assert_allclose(stats, g[f"{ref_name}_stats"], rtol=1e-5, atol=1e-6)
+
+
+def test_default_config_160(golden):
+    g = golden("g6_default_160.npz")
+    vol = synthetic.synth_volume((160, 160, 160), seed=0)
+    model = oracle.OracleModel(synthetic.synth_state_dict(3, 1, seed=1))
+    pred = oracle.predict(vol, model, batch_size=8)
+    np.testing.assert_allclose(
+        pred[:, ::5, ::5, ::5], g["pred_sub"], rtol=0, atol=5e-6
+    )
+    np.testing.assert_allclose(pred[:, 80, 81, :], g["pred_line"], rtol=0, atol=5e-6)
+    zero = (pred == 0).all(axis=0)
+    assert abs(zero.mean() - float(g["zero_fraction"])) < 1e-12
+    np.testing.assert_array_equal(zero.all(axis=(1, 2)), g["zero_z"])
+    np.testing.assert_array_equal(zero.all(axis=(0, 2)), g["zero_y"])
+    np.testing.assert_array_equal(zero.all(axis=(0, 1)), g["zero_x"])
+
+
+def test_full_width_small_patches(golden):
+    g = golden("g5_fullwidth_small.npz")
+    vol = synthetic.synth_volume((72, 40, 56), seed=11)
+    model = oracle.OracleModel(synthetic.synth_state_dict(3, 1, seed=1))
+    pred = oracle.predict(
+        vol, model, batch_size=4, patch_shape=(32, 32, 32), overlap=(8, 8, 8), trim=4
+    )
+    np.testing.assert_allclose(pred[:, ::2, ::2, ::2], g["pred"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(pred[:, 30, 20, :], g["pred_row"], rtol=0, atol=5e-6)
+    model1 = oracle.OracleModel(synthetic.synth_state_dict(1, 1, seed=4))
+    pred1 = oracle.predict(
+        vol, model1, affinity_mode=False, batch_size=5, patch_shape=(32, 32, 32),
+        overlap=(16, 16, 16), trim=2,
+    )
+    np.testing.assert_allclose(pred1[::2, ::2, ::2], g["pred_fg"], rtol=0, atol=5e-6)
