@@ -1,0 +1,106 @@
+// Shared declarations of the exaspim_affinity HIP extension (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/exaspim_affinity.h"
+
+namespace exaspim {
+
+// ---- error reporting (thread-local message behind exaspim_last_error) ----
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define EXA_CHECK_ARG(cond, ...)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            ::exaspim::set_error(__VA_ARGS__);   \
+            return EXASPIM_E_INVALID;            \
+        }                                        \
+    } while (0)
+
+#define EXA_CHECK_HIP(expr)                                                  \
+    do {                                                                     \
+        hipError_t _e = (expr);                                              \
+        if (_e != hipSuccess) {                                              \
+            ::exaspim::set_error("%s failed: %s (%s:%d)", #expr,             \
+                                 hipGetErrorString(_e), __FILE__, __LINE__); \
+            return EXASPIM_E_HIP;                                            \
+        }                                                                    \
+    } while (0)
+
+// ---- network plan ---------------------------------------------------------
+// Channel counts are padded to multiples of 32 inside the workspace so that
+// every MFMA convolution sees whole 32-wide output tiles and whole 32-byte
+// input chunks; padded weights and biases are zero, so padded channels carry
+// exact zeros through LeakyReLU, max-pool and interpolation.
+constexpr int kChannelPad = 32;
+constexpr int kNumMfmaConvs = 17;  // every 3x3x3 conv except inc.0 (Cin = 1)
+
+inline int pad_channels(int c) { return (c + kChannelPad - 1) / kChannelPad * kChannelPad; }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int dtype_size(int dtype) { return dtype == EXASPIM_DT_F32 ? 4 : 2; }
+
+struct ConvLayer {
+    int ca_real = 0, cb_real = 0;  // real input channels from source A / B
+    int ca = 0, cb = 0;            // padded
+    int cout_real = 0, cout = 0;   // real / padded output channels
+    size_t w_off = 0;              // packed weights (compute dtype), bytes
+    size_t b_off = 0;              // folded bias, float[cout], bytes
+    size_t p_off = 0;              // offset of this conv's block in params
+};
+
+struct UNetPlan {
+    int channels[5] = {0, 0, 0, 0, 0};
+    int out_channels = 0;
+    int dtype = 0;
+    int c0 = 0, c0p = 0;            // inc.0 output channels real / padded
+    size_t first_p_off = 0;         // params offset of inc.0
+    size_t first_w_off = 0;         // float[27][c0p]
+    size_t first_b_off = 0;         // float[c0p]
+    ConvLayer conv[kNumMfmaConvs];  // inc.3, down1.0 ... up4.3
+    size_t head_p_off = 0;
+    size_t head_w_off = 0;          // float[out_channels][c0p]
+    size_t head_b_off = 0;          // float[out_channels]
+    size_t packed_bytes = 0;
+    size_t n_params = 0;
+};
+
+// Builds the plan; returns false (and sets the error) on invalid arguments.
+bool make_plan(const int32_t channels[5], int32_t out_channels, int32_t dtype,
+               UNetPlan* plan);
+
+int pack_weights(const UNetPlan& plan, const float* params, void* packed_host);
+
+// ---- kernel launchers (conv3d.hip / layers.hip / prepost.hip) -------------
+struct ConvArgs {
+    const void* src_a;
+    const void* src_b;
+    int ca, cb;          // padded channel counts of the two sources (cb may be 0)
+    const void* weights; // packed fragments
+    const float* bias;
+    void* dst;
+    int cout;            // padded
+    int n, d, h, w;      // batch of patches and their spatial size at this level
+    float slope;
+};
+
+int launch_conv3x3x3(int dtype, const ConvArgs& a, hipStream_t stream);
+
+int launch_conv_first(int dtype, const float* x, const float* w, const float* bias,
+                      void* dst, int n, int d, int h, int wd, int c0p, float slope,
+                      hipStream_t stream);
+int launch_maxpool2(int dtype, const void* src, void* dst, int n, int d, int h, int w,
+                    int c, hipStream_t stream);  // d,h,w = INPUT size
+int launch_upsample2(int dtype, const void* src, void* dst, int n, int d, int h, int w,
+                     int c, hipStream_t stream);  // d,h,w = INPUT size
+int launch_head(int dtype, const void* src, const float* w, const float* bias,
+                float* out, int n, int d, int h, int wd, int c0p, int out_channels,
+                int apply_sigmoid, hipStream_t stream);
+
+}  // namespace exaspim

@@ -1,0 +1,265 @@
+// 3x3x3 convolution (+ folded BatchNorm bias + LeakyReLU) as an implicit GEMM
+// on the gfx950 matrix cores. Replaces every nn.Conv3d(k=3,p=1) ->
+// BatchNorm3d(eval) -> LeakyReLU(0.01) triple of the reference's DoubleConv
+// (machine_learning/unet3d.py:142-149) except inc.0 (Cin = 1, layers.hip), and
+// torch.cat([skip, up], dim=1) (unet3d.py:288) by reading two sources.
+//
+// Layout. Activations are channels-last (N, D, H, W, C) with C padded to 32.
+// One workgroup owns a TZ x TY x TX block of output voxels of one patch and
+// NWG = WAVES_N * NT * 32 output channels. The K dimension (27 taps x Cin) is
+// walked in chunks of 32 bytes of input channels (8 x f32 / 16 x 16-bit): per
+// chunk the (TZ+2)(TY+2)(TX+2) halo block is staged in LDS as two planes of
+// 16-byte channel groups, [group][halo voxel]; zero padding at patch borders
+// is written as zeros. A wave's MFMA B operand (activations, voxel on the lane)
+// is then ONE ds_read_b128 per (tap, 32 voxels): lanes 0-31 read plane 0, lanes
+// 32-63 plane 1, 32 consecutive voxels -> conflict-free. The A operand
+// (weights) comes straight from global memory in fragment order (plan.cpp), 1
+// KiB per wave-instruction, shared by all MT voxel tiles of the wave.
+//
+// D = W(32 cout x K) * X(K x 32 voxels): the accumulator keeps the voxel on
+// the lane and 4-channel runs in registers, so the epilogue stores 16 bytes
+// (f32) / 8 bytes (16-bit) of consecutive channels per lane.
+//
+// f32 uses v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 4 per chunk-tap),
+// bf16/f16 use v_mfma_f32_32x32x16_{bf16,f16} (one per chunk-tap).
+
+#include "common.h"
+
+namespace exaspim {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct F32Tag { static constexpr int kG = 4; };
+struct BF16Tag { static constexpr int kG = 8; };
+struct F16Tag { static constexpr int kG = 8; };
+
+template <typename Tag>
+__device__ __forceinline__ void mma(f32x16& acc, const uint4& wf, const uint4& xf);
+
+template <>
+__device__ __forceinline__ void mma<F32Tag>(f32x16& acc, const uint4& wf, const uint4& xf) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wf.x), __uint_as_float(xf.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wf.y), __uint_as_float(xf.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wf.z), __uint_as_float(xf.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wf.w), __uint_as_float(xf.w), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma<BF16Tag>(f32x16& acc, const uint4& wf, const uint4& xf) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf),
+                                                  __builtin_bit_cast(bf16x8, xf), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma<F16Tag>(f32x16& acc, const uint4& wf, const uint4& xf) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf),
+                                                 __builtin_bit_cast(f16x8, xf), acc, 0, 0, 0);
+}
+
+// store 4 consecutive output channels of one voxel
+template <typename Tag>
+__device__ __forceinline__ void store4(void* dst, size_t elem_off, float a, float b, float c, float d);
+template <>
+__device__ __forceinline__ void store4<F32Tag>(void* dst, size_t off, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(static_cast<float*>(dst) + off) = make_float4(a, b, c, d);
+}
+template <>
+__device__ __forceinline__ void store4<BF16Tag>(void* dst, size_t off, float a, float b, float c, float d) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+    *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(dst) + off) = v;
+}
+template <>
+__device__ __forceinline__ void store4<F16Tag>(void* dst, size_t off, float a, float b, float c, float d) {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    f16x4 v = {(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d};
+    *reinterpret_cast<f16x4*>(static_cast<_Float16*>(dst) + off) = v;
+}
+
+template <typename Tag, int TZ, int TY, int TX, int WAVES_M, int WAVES_N, int MT, int NT, int MINW>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_kernel(
+    ConvArgs a, int tiles_z, int tiles_y, int tiles_x) {
+    constexpr int G = Tag::kG;            // elements per 16 B
+    constexpr int KC = 2 * G;             // channels per chunk
+    constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+    constexpr int HV = HZ * HY * HX;      // halo voxels
+    constexpr int HVP = (HV + 1) & ~1;    // plane stride (16-byte units)
+    constexpr int NTHREADS = WAVES_M * WAVES_N * 64;
+    constexpr int TILE_VOX = TZ * TY * TX;
+    static_assert(WAVES_M * MT * 32 >= TILE_VOX, "tile not covered by the waves");
+
+    __shared__ uint4 lds[2 * HVP];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N;
+    const int wn = wave % WAVES_N;
+    const int half = lane >> 5;
+    const int r = lane & 31;
+
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y; bid /= tiles_y;
+    const int tz = bid % tiles_z; bid /= tiles_z;
+    const int nb = bid;  // patch index in the batch
+    const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
+
+    const int ntiles = a.cout >> 5;
+    const int ntile0 = (blockIdx.y * WAVES_N + wn) * NT;
+
+    int base[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int m = (wm * MT + mt) * 32 + r;
+        m = m < TILE_VOX ? m : TILE_VOX - 1;
+        const int z = m / (TY * TX), y = (m / TX) % TY, x = m % TX;
+        base[mt] = (z * HY + y) * HX + x + half * HVP;
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+
+    const int nchunks = (a.ca + a.cb) / KC;
+    const int es = 16 / G;
+    for (int c = 0; c < nchunks; ++c) {
+        const char* src;
+        int cs, ch0;
+        if (c * KC < a.ca) {
+            src = static_cast<const char*>(a.src_a); cs = a.ca; ch0 = c * KC;
+        } else {
+            src = static_cast<const char*>(a.src_b); cs = a.cb; ch0 = c * KC - a.ca;
+        }
+        __syncthreads();  // every wave is done reading the previous chunk
+        for (int i = tid; i < 2 * HV; i += NTHREADS) {
+            const int kg = i >= HV ? 1 : 0;
+            const int hv = i - kg * HV;
+            const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
+            const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if ((unsigned)gz < (unsigned)a.d && (unsigned)gy < (unsigned)a.h &&
+                (unsigned)gx < (unsigned)a.w) {
+                const size_t vox = (((size_t)nb * a.d + gz) * a.h + gy) * a.w + gx;
+                v = *reinterpret_cast<const uint4*>(src + (vox * cs + ch0 + kg * G) * es);
+            }
+            lds[kg * HVP + hv] = v;
+        }
+        __syncthreads();
+
+        const uint4* wp = static_cast<const uint4*>(a.weights) +
+                          ((size_t)c * 27 * ntiles + ntile0) * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            constexpr int dummy = 0; (void)dummy;
+            const int tapoff = ((t / 9) * HY + (t / 3) % 3) * HX + t % 3;
+            uint4 wf[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[nt] = wp[((size_t)t * ntiles + nt) * 64];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const uint4 xf = lds[base[mt] + tapoff];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) mma<Tag>(acc[mt][nt], wf[nt], xf);
+            }
+        }
+    }
+
+    // epilogue: bias + LeakyReLU (unet3d.py:145,148), 4-channel runs per lane
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = (wm * MT + mt) * 32 + r;
+        const int z = m / (TY * TX), y = (m / TX) % TY, x = m % TX;
+        const int gz = z0 + z, gy = y0 + y, gx = x0 + x;
+        const bool ok = m < TILE_VOX && gz < a.d && gy < a.h && gx < a.w;
+        if (!ok) continue;
+        const size_t vox = (((size_t)nb * a.d + gz) * a.h + gy) * a.w + gx;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int co = (ntile0 + nt) * 32 + 8 * q + 4 * half;
+                const float4 b = *reinterpret_cast<const float4*>(a.bias + co);
+                float v0 = acc[mt][nt][4 * q + 0] + b.x;
+                float v1 = acc[mt][nt][4 * q + 1] + b.y;
+                float v2 = acc[mt][nt][4 * q + 2] + b.z;
+                float v3 = acc[mt][nt][4 * q + 3] + b.w;
+                v0 = v0 > 0.f ? v0 : v0 * a.slope;
+                v1 = v1 > 0.f ? v1 : v1 * a.slope;
+                v2 = v2 > 0.f ? v2 : v2 * a.slope;
+                v3 = v3 > 0.f ? v3 : v3 * a.slope;
+                store4<Tag>(a.dst, vox * a.cout + co, v0, v1, v2, v3);
+            }
+        }
+    }
+}
+
+// ---- host side: pick a tile configuration per layer -----------------------
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+template <typename Tag, int TZ, int TY, int TX, int WAVES_M, int WAVES_N, int MT, int NT, int MINW>
+static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
+    constexpr int NWG = WAVES_N * NT * 32;
+    if (a.cout % NWG != 0) {
+        set_error("conv: cout %d not a multiple of the %d-channel tile", a.cout, NWG);
+        return EXASPIM_E_INVALID;
+    }
+    const int tz = cdiv(a.d, TZ), ty = cdiv(a.h, TY), tx = cdiv(a.w, TX);
+    const long long blocks = (long long)tz * ty * tx * a.n;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) {
+        set_error("conv: grid of %lld blocks out of range", blocks);
+        return EXASPIM_E_INVALID;
+    }
+    dim3 grid((unsigned)blocks, a.cout / NWG);
+    conv3x3x3_kernel<Tag, TZ, TY, TX, WAVES_M, WAVES_N, MT, NT, MINW>
+        <<<grid, WAVES_M * WAVES_N * 64, 0, stream>>>(a, tz, ty, tx);
+    EXA_CHECK_HIP(hipGetLastError());
+    return EXASPIM_OK;
+}
+
+template <typename Tag>
+static int launch_typed(const ConvArgs& a, hipStream_t stream) {
+    // Widest x extent first: the tile shapes follow the 96/48/24/12/6 pyramid of
+    // a 96^3 patch; any other size runs on the closest shape with masking.
+    if (a.w >= 32 && a.w % 32 == 0) {
+        if (a.cout % 64 == 0)
+            return launch_cfg<Tag, 4, 8, 32, 4, 1, 8, 1, 2>(a, stream);  // grid.y = cout/32
+        return launch_cfg<Tag, 4, 8, 32, 4, 1, 8, 1, 2>(a, stream);
+    }
+    if (a.w >= 16 && a.w % 16 == 0) {
+        if (a.cout % 64 == 0) return launch_cfg<Tag, 4, 8, 16, 4, 1, 4, 2, 2>(a, stream);
+        return launch_cfg<Tag, 4, 8, 16, 4, 1, 4, 1, 2>(a, stream);
+    }
+    if (a.w > 12) {
+        if (a.cout % 64 == 0) return launch_cfg<Tag, 4, 4, 24, 4, 1, 3, 2, 2>(a, stream);
+        return launch_cfg<Tag, 4, 4, 24, 4, 1, 3, 1, 2>(a, stream);
+    }
+    if (a.w > 6) {
+        if (a.cout % 128 == 0) return launch_cfg<Tag, 4, 4, 12, 2, 2, 3, 2, 2>(a, stream);
+        if (a.cout % 64 == 0) return launch_cfg<Tag, 4, 4, 12, 2, 2, 3, 1, 2>(a, stream);
+        return launch_cfg<Tag, 4, 4, 12, 2, 1, 3, 1, 2>(a, stream);
+    }
+    if (a.cout % 64 == 0) return launch_cfg<Tag, 6, 6, 6, 2, 2, 4, 1, 2>(a, stream);
+    return launch_cfg<Tag, 6, 6, 6, 2, 1, 4, 1, 2>(a, stream);
+}
+
+int launch_conv3x3x3(int dtype, const ConvArgs& a, hipStream_t stream) {
+    const int kc = dtype == EXASPIM_DT_F32 ? 8 : 16;
+    EXA_CHECK_ARG(a.ca % kc == 0 && a.cb % kc == 0 && a.cout % 32 == 0 && a.ca > 0,
+                  "conv: channels (%d,%d)->%d not padded", a.ca, a.cb, a.cout);
+    EXA_CHECK_ARG(a.n > 0 && a.d > 0 && a.h > 0 && a.w > 0, "conv: empty input");
+    switch (dtype) {
+        case EXASPIM_DT_F32: return launch_typed<F32Tag>(a, stream);
+        case EXASPIM_DT_BF16: return launch_typed<BF16Tag>(a, stream);
+        case EXASPIM_DT_F16: return launch_typed<F16Tag>(a, stream);
+    }
+    set_error("conv: unknown dtype %d", dtype);
+    return EXASPIM_E_INVALID;
+}
+
+}  // namespace exaspim

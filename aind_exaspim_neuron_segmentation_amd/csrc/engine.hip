@@ -1,0 +1,212 @@
+// UNet3D.forward (machine_learning/unet3d.py:77-105) as a fixed sequence of
+// kernel launches on the caller's stream, plus the extern "C" model API.
+//
+// Workspace: per pyramid level l (voxels n*d*h*w / 8^l) three channels-last
+// buffers -- skip[l] (x1..x4, alive until the decoder consumes them), A[l] and
+// B[l] (ping-pong) -- each sized for the widest tensor stored at that level.
+
+#include <algorithm>
+#include <new>
+#include <string_view>
+
+#include "common.h"
+
+namespace exaspim {
+
+constexpr float kLeakySlope = 0.01f;  // unet3d.py:145,148
+
+struct Workspace {
+    size_t skip[5], a[5], b[5];
+    size_t bytes;
+};
+
+}  // namespace exaspim
+
+struct exaspim_unet {
+    exaspim::UNetPlan plan;
+    int device;
+    const char* packed;  // device image (caller-owned)
+};
+
+namespace exaspim {
+
+static bool level_dims_ok(int d, int h, int w) {
+    return d > 0 && h > 0 && w > 0 && d % 16 == 0 && h % 16 == 0 && w % 16 == 0;
+}
+
+static Workspace make_workspace(const UNetPlan& p, int n, int d, int h, int w) {
+    const int* c = p.channels;
+    const int c0 = pad_channels(c[0]), c1 = pad_channels(c[1]), c2 = pad_channels(c[2]),
+              c3 = pad_channels(c[3]), h4 = pad_channels(c[4] / 2);
+    const int y1c = pad_channels(c[3] / 2), y2c = pad_channels(c[2] / 2),
+              y3c = pad_channels(c[1] / 2);
+    const int maxc[5] = {
+        std::max(c0, y3c),
+        std::max(std::max(c0, c1), std::max(y2c, y3c)),
+        std::max(std::max(c1, c2), std::max(y1c, y2c)),
+        std::max(std::max(c2, c3), std::max(h4, y1c)),
+        std::max(c3, h4),
+    };
+    const size_t es = dtype_size(p.dtype);
+    Workspace ws;
+    size_t off = 0;
+    for (int l = 0; l < 5; ++l) {
+        const size_t vox = (size_t)n * (d >> l) * (h >> l) * (w >> l);
+        const size_t sz = align_up(vox * maxc[l] * es, 256);
+        ws.skip[l] = off; off += (l < 4 ? sz : 0);
+        ws.a[l] = off; off += sz;
+        ws.b[l] = off; off += sz;
+    }
+    ws.bytes = off;
+    return ws;
+}
+
+static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, int h, int w,
+                   int apply_sigmoid, void* workspace, size_t workspace_bytes,
+                   hipStream_t stream) {
+    const UNetPlan& p = e->plan;
+    const Workspace ws = make_workspace(p, n, d, h, w);
+    if (workspace_bytes < ws.bytes) {
+        set_error("forward: workspace %zu bytes < required %zu", workspace_bytes, ws.bytes);
+        return EXASPIM_E_WORKSPACE;
+    }
+    char* base = static_cast<char*>(workspace);
+    auto skip = [&](int l) { return (void*)(base + ws.skip[l]); };
+    auto A = [&](int l) { return (void*)(base + ws.a[l]); };
+    auto B = [&](int l) { return (void*)(base + ws.b[l]); };
+    const int dt = p.dtype;
+    int rc;
+
+    auto conv = [&](int idx, const void* sa, const void* sb, void* dst, int l) -> int {
+        const ConvLayer& L = p.conv[idx];
+        ConvArgs a;
+        a.src_a = sa; a.src_b = sb; a.ca = L.ca; a.cb = L.cb;
+        a.weights = e->packed + L.w_off;
+        a.bias = reinterpret_cast<const float*>(e->packed + L.b_off);
+        a.dst = dst; a.cout = L.cout;
+        a.n = n; a.d = d >> l; a.h = h >> l; a.w = w >> l;
+        a.slope = kLeakySlope;
+        return launch_conv3x3x3(dt, a, stream);
+    };
+#define RUN(expr) do { rc = (expr); if (rc) return rc; } while (0)
+
+    // encoder (unet3d.py:93-97)
+    RUN(launch_conv_first(dt, x, reinterpret_cast<const float*>(e->packed + p.first_w_off),
+                          reinterpret_cast<const float*>(e->packed + p.first_b_off), A(0), n, d,
+                          h, w, p.c0p, kLeakySlope, stream));
+    RUN(conv(0, A(0), nullptr, skip(0), 0));                      // x1
+    for (int l = 1; l <= 4; ++l) {
+        const ConvLayer& L0 = p.conv[2 * l - 1];
+        const void* prev = skip(l - 1);
+        RUN(launch_maxpool2(dt, prev, A(l), n, d >> (l - 1), h >> (l - 1), w >> (l - 1), L0.ca,
+                            stream));
+        RUN(conv(2 * l - 1, A(l), nullptr, B(l), l));
+        RUN(conv(2 * l, B(l), nullptr, l < 4 ? skip(l) : A(l), l));  // x2..x4, x5 in A(4)
+    }
+    // decoder (unet3d.py:100-103): y = DoubleConv(cat[skip, up(prev)])
+    const void* prev = A(4);
+    for (int l = 3; l >= 0; --l) {
+        const int i0 = 9 + 2 * (3 - l);  // up1.0 = conv[9], up2.0 = conv[11], ...
+        const ConvLayer& L0 = p.conv[i0];
+        RUN(launch_upsample2(dt, prev, A(l), n, d >> (l + 1), h >> (l + 1), w >> (l + 1), L0.cb,
+                             stream));
+        RUN(conv(i0, skip(l), A(l), B(l), l));
+        RUN(conv(i0 + 1, B(l), nullptr, A(l), l));
+        prev = A(l);
+    }
+    RUN(launch_head(dt, prev, reinterpret_cast<const float*>(e->packed + p.head_w_off),
+                    reinterpret_cast<const float*>(e->packed + p.head_b_off), out, n, d, h, w,
+                    p.c0p, p.out_channels, apply_sigmoid, stream));
+#undef RUN
+    return EXASPIM_OK;
+}
+
+}  // namespace exaspim
+
+using namespace exaspim;
+
+extern "C" int exaspim_abi_version(void) { return EXASPIM_ABI_VERSION; }
+extern "C" const char* exaspim_last_error(void) { return get_error(); }
+
+extern "C" size_t exaspim_unet_param_count(const int32_t channels[5], int32_t out_channels) {
+    UNetPlan p;
+    if (!make_plan(channels, out_channels, EXASPIM_DT_F32, &p)) return 0;
+    return p.n_params;
+}
+
+extern "C" size_t exaspim_unet_packed_bytes(const int32_t channels[5], int32_t out_channels,
+                                            int32_t dtype) {
+    UNetPlan p;
+    if (!make_plan(channels, out_channels, dtype, &p)) return 0;
+    return p.packed_bytes;
+}
+
+extern "C" int exaspim_unet_pack_weights(const int32_t channels[5], int32_t out_channels,
+                                         int32_t dtype, const float* params, size_t n_params,
+                                         void* packed_host, size_t packed_bytes) {
+    UNetPlan p;
+    if (!make_plan(channels, out_channels, dtype, &p)) return EXASPIM_E_INVALID;
+    EXA_CHECK_ARG(params && packed_host, "pack_weights: NULL pointer");
+    EXA_CHECK_ARG(n_params == p.n_params, "pack_weights: got %zu parameters, expected %zu",
+                  n_params, p.n_params);
+    EXA_CHECK_ARG(packed_bytes == p.packed_bytes, "pack_weights: buffer %zu bytes, expected %zu",
+                  packed_bytes, p.packed_bytes);
+    return pack_weights(p, params, packed_host);
+}
+
+extern "C" int exaspim_unet_create(const int32_t channels[5], int32_t out_channels,
+                                   int32_t dtype, int32_t device, const void* packed_dev,
+                                   size_t packed_bytes, exaspim_unet** out) {
+    EXA_CHECK_ARG(out != nullptr && packed_dev != nullptr, "create: NULL pointer");
+    UNetPlan p;
+    if (!make_plan(channels, out_channels, dtype, &p)) return EXASPIM_E_INVALID;
+    EXA_CHECK_ARG(packed_bytes == p.packed_bytes, "create: packed image %zu bytes, expected %zu",
+                  packed_bytes, p.packed_bytes);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        set_error("create: device %d not available (%d HIP devices visible)", device, ndev);
+        return EXASPIM_E_NODEVICE;
+    }
+    hipDeviceProp_t prop;
+    EXA_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::string_view(prop.gcnArchName).substr(0, 6) != "gfx950") {
+        set_error("create: device %d is %s; this library is built for gfx950 only", device,
+                  prop.gcnArchName);
+        return EXASPIM_E_NODEVICE;
+    }
+    exaspim_unet* e = new (std::nothrow) exaspim_unet;
+    EXA_CHECK_ARG(e != nullptr, "create: out of host memory");
+    e->plan = p;
+    e->device = device;
+    e->packed = static_cast<const char*>(packed_dev);
+    *out = e;
+    return EXASPIM_OK;
+}
+
+extern "C" void exaspim_unet_destroy(exaspim_unet* h) { delete h; }
+
+extern "C" size_t exaspim_unet_workspace_bytes(const exaspim_unet* h, int32_t n, int32_t d,
+                                               int32_t hgt, int32_t w) {
+    if (!h || n <= 0 || !level_dims_ok(d, hgt, w)) {
+        set_error("workspace_bytes: bad arguments (n %d, patch %dx%dx%d must be multiples of 16)",
+                  n, d, hgt, w);
+        return 0;
+    }
+    return make_workspace(h->plan, n, d, hgt, w).bytes;
+}
+
+extern "C" int exaspim_unet_forward(exaspim_unet* h, const float* x_dev, float* out_dev,
+                                    int32_t n, int32_t d, int32_t hgt, int32_t w,
+                                    int32_t apply_sigmoid, void* workspace_dev,
+                                    size_t workspace_bytes, void* stream) {
+    EXA_CHECK_ARG(h && x_dev && out_dev && workspace_dev, "forward: NULL pointer");
+    EXA_CHECK_ARG(n > 0, "forward: empty batch");
+    // The reference's Up.forward pads only two axes by the wrong differences
+    // (unet3d.py:281-287), so torch.cat raises for sizes that are not multiples
+    // of 16; the same sizes are rejected here.
+    EXA_CHECK_ARG(level_dims_ok(d, hgt, w),
+                  "forward: patch %dx%dx%d: every dimension must be a positive multiple of 16",
+                  d, hgt, w);
+    return forward(h, x_dev, out_dev, n, d, hgt, w, apply_sigmoid, workspace_dev, workspace_bytes,
+                   (hipStream_t)stream);
+}

@@ -1,0 +1,393 @@
+// Device-side pre/post-processing of predict() (inference.py:79-126), all
+// HBM-bound byte/float streaming:
+//   histogram         -> exact order statistics for np.percentile (img_util.py:526)
+//   gather_patches    -> np.minimum + normalize + get_patch_slices + reflect
+//                        add_padding + float32 cast (inference.py:79-80,188-192)
+//   stitch_accumulate -> trimmed overlap-add (inference.py:99-116)
+//   stitch_finalize   -> divide by the patch count (inference.py:120-125)
+//   synth_volume_u16  -> benchmark / test input (utils/synthetic.py)
+
+#include "common.h"
+
+namespace exaspim {
+
+// ---------------------------------------------------------------- synthetic --
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    unsigned long long z = x + 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void synth_kernel(uint16_t* __restrict__ vol, exaspim_block blk,
+                                                    unsigned long long seed) {
+    const size_t total = (size_t)blk.dims[0] * blk.dims[1] * blk.dims[2];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % blk.dims[2]);
+        size_t t = i / blk.dims[2];
+        const int y = (int)(t % blk.dims[1]);
+        const int z = (int)(t / blk.dims[1]);
+        const unsigned long long lin =
+            ((unsigned long long)(z + blk.origin[0]) * blk.global[1] + (y + blk.origin[1])) *
+                blk.global[2] + (x + blk.origin[2]);
+        vol[i] = (uint16_t)(splitmix64(lin + seed) % 2000ULL);
+    }
+}
+
+// ---------------------------------------------------------------- histogram --
+__device__ __forceinline__ unsigned f32_key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // order-preserving
+}
+
+// bin of one voxel, or -1 if it does not take part in this pass
+template <int VOX>
+__device__ __forceinline__ int bin_of(const void* vol, size_t i, double clip, int has_clip,
+                                      int pass, unsigned prefix);
+template <>
+__device__ __forceinline__ int bin_of<EXASPIM_VOX_U8>(const void* vol, size_t i, double clip,
+                                                      int has_clip, int, unsigned) {
+    int v = static_cast<const uint8_t*>(vol)[i];
+    if (has_clip && (double)v > clip) v = (int)clip;
+    return v;
+}
+template <>
+__device__ __forceinline__ int bin_of<EXASPIM_VOX_U16>(const void* vol, size_t i, double clip,
+                                                       int has_clip, int, unsigned) {
+    int v = static_cast<const uint16_t*>(vol)[i];
+    if (has_clip && (double)v > clip) v = (int)clip;
+    return v;
+}
+template <>
+__device__ __forceinline__ int bin_of<EXASPIM_VOX_I16>(const void* vol, size_t i, double clip,
+                                                       int has_clip, int, unsigned) {
+    int v = static_cast<const int16_t*>(vol)[i];
+    if (has_clip && (double)v > clip) v = (int)clip;
+    return v + 32768;
+}
+template <>
+__device__ __forceinline__ int bin_of<EXASPIM_VOX_F32>(const void* vol, size_t i, double clip,
+                                                       int has_clip, int pass, unsigned prefix) {
+    float v = static_cast<const float*>(vol)[i];
+    if (has_clip) v = fminf(v, (float)clip);
+    const unsigned k = f32_key(v);
+    if (pass == 0) return (int)(k >> 16);
+    return (k >> 16) == prefix ? (int)(k & 0xffffu) : -1;
+}
+
+constexpr int kLdsBins = 16384;  // privatised window of the 65536 bins
+
+template <int VOX>
+__global__ __launch_bounds__(256) void histogram_kernel(const void* __restrict__ vol, size_t n,
+                                                        double clip, int has_clip, int pass,
+                                                        unsigned prefix, int window_lo,
+                                                        unsigned long long* __restrict__ hist) {
+    __shared__ unsigned local[kLdsBins];
+    for (int i = threadIdx.x; i < kLdsBins; i += blockDim.x) local[i] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int b = bin_of<VOX>(vol, i, clip, has_clip, pass, prefix);
+        if (b < 0) continue;
+        const int lb = b - window_lo;
+        if ((unsigned)lb < (unsigned)kLdsBins)
+            atomicAdd(&local[lb], 1u);
+        else
+            atomicAdd(&hist[b], 1ULL);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kLdsBins; i += blockDim.x) {
+        const unsigned c = local[i];
+        if (c) atomicAdd(&hist[window_lo + i], (unsigned long long)c);
+    }
+}
+
+// ------------------------------------------------------------------- gather --
+__device__ __forceinline__ int reflect_index(int j, int n) {
+    // numpy 'reflect' on the high side of a length-n axis (period 2(n-1))
+    if (n == 1) return 0;
+    const int p = 2 * (n - 1);
+    const int m = j % p;
+    return m < n ? m : p - m;
+}
+
+template <int VOX>
+__device__ __forceinline__ double load_voxel(const void* vol, size_t i);
+template <> __device__ __forceinline__ double load_voxel<EXASPIM_VOX_U8>(const void* v, size_t i) { return (double)static_cast<const uint8_t*>(v)[i]; }
+template <> __device__ __forceinline__ double load_voxel<EXASPIM_VOX_U16>(const void* v, size_t i) { return (double)static_cast<const uint16_t*>(v)[i]; }
+template <> __device__ __forceinline__ double load_voxel<EXASPIM_VOX_I16>(const void* v, size_t i) { return (double)static_cast<const int16_t*>(v)[i]; }
+template <> __device__ __forceinline__ double load_voxel<EXASPIM_VOX_F32>(const void* v, size_t i) { return (double)static_cast<const float*>(v)[i]; }
+
+template <int VOX>
+__global__ __launch_bounds__(256) void gather_kernel(const void* __restrict__ vol,
+                                                     exaspim_block blk,
+                                                     const int* __restrict__ starts, int n, int pz,
+                                                     int py, int px, double clip, int has_clip,
+                                                     double mn, double denom,
+                                                     float* __restrict__ out) {
+    const size_t pvox = (size_t)pz * py * px;
+    const size_t total = pvox * n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i / pvox);
+        size_t t = i % pvox;
+        const int x = (int)(t % px); t /= px;
+        const int y = (int)(t % py);
+        const int z = (int)(t / py);
+        const int sz = starts[3 * p], sy = starts[3 * p + 1], sx = starts[3 * p + 2];
+        // in-volume extent of the patch (img_util.py:424-428), then reflect
+        const int nz = min(sz + pz, blk.global[0]) - sz;
+        const int ny = min(sy + py, blk.global[1]) - sy;
+        const int nx = min(sx + px, blk.global[2]) - sx;
+        const int lz = sz + reflect_index(z, nz) - blk.origin[0];
+        const int ly = sy + reflect_index(y, ny) - blk.origin[1];
+        const int lx = sx + reflect_index(x, nx) - blk.origin[2];
+        float r = 0.f;
+        if ((unsigned)lz < (unsigned)blk.dims[0] && (unsigned)ly < (unsigned)blk.dims[1] &&
+            (unsigned)lx < (unsigned)blk.dims[2]) {
+            double v = load_voxel<VOX>(vol, ((size_t)lz * blk.dims[1] + ly) * blk.dims[2] + lx);
+            if (has_clip) v = fmin(v, clip);
+            double q = (v - mn) / denom;         // float64, like numpy (img_util.py:527)
+            q = fmin(fmax(q, 0.0), 1.0);         // np.clip(img, 0, 1)
+            r = (float)q;                        // cast on assignment (inference.py:191)
+        }
+        out[i] = r;
+    }
+}
+
+// ------------------------------------------------------------------- stitch --
+struct Coverage {
+    int lo[3], hi[3];
+};
+
+__device__ __forceinline__ bool covered(const int* s, const exaspim_window& w, const int g[3],
+                                        int z, int y, int x) {
+    const int oz = w.patch[0] - 2 * w.trim, oy = w.patch[1] - 2 * w.trim,
+              ox = w.patch[2] - 2 * w.trim;
+    const int z0 = s[0] + w.trim, y0 = s[1] + w.trim, x0 = s[2] + w.trim;
+    return z >= z0 && z < min(z0 + oz, g[0]) && y >= y0 && y < min(y0 + oy, g[1]) && x >= x0 &&
+           x < min(x0 + ox, g[2]);
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void stitch_kernel(const float* __restrict__ pred,
+                                                     const int* __restrict__ starts, int n,
+                                                     exaspim_window win,
+                                                     float* __restrict__ accum,
+                                                     exaspim_block blk) {
+    const int oz = win.patch[0] - 2 * win.trim, oy = win.patch[1] - 2 * win.trim,
+              ox = win.patch[2] - 2 * win.trim;
+    const size_t ovox = (size_t)oz * oy * ox;
+    const size_t pvox = (size_t)win.patch[0] * win.patch[1] * win.patch[2];
+    const size_t avox = (size_t)blk.dims[0] * blk.dims[1] * blk.dims[2];
+    const size_t total = ovox * n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i / ovox);
+        size_t t = i % ovox;
+        const int x = (int)(t % ox); t /= ox;
+        const int y = (int)(t % oy);
+        const int z = (int)(t / oy);
+        const int* sp = starts + 3 * p;
+        const int gz = sp[0] + win.trim + z, gy = sp[1] + win.trim + y, gx = sp[2] + win.trim + x;
+        if (gz >= blk.global[0] || gy >= blk.global[1] || gx >= blk.global[2]) continue;
+        const int lz = gz - blk.origin[0], ly = gy - blk.origin[1], lx = gx - blk.origin[2];
+        if ((unsigned)lz >= (unsigned)blk.dims[0] || (unsigned)ly >= (unsigned)blk.dims[1] ||
+            (unsigned)lx >= (unsigned)blk.dims[2])
+            continue;
+        // The first patch of the batch that covers this voxel owns it and adds
+        // every covering patch in batch order (= the reference's loop order).
+        bool owner = true;
+        for (int j = 0; j < p; ++j)
+            if (covered(starts + 3 * j, win, blk.global, gz, gy, gx)) { owner = false; break; }
+        if (!owner) continue;
+        const size_t a = ((size_t)lz * blk.dims[1] + ly) * blk.dims[2] + lx;
+        float s[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) s[c] = accum[c * avox + a];
+        for (int j = p; j < n; ++j) {
+            const int* sj = starts + 3 * j;
+            if (j != p && !covered(sj, win, blk.global, gz, gy, gx)) continue;
+            const int pz = gz - sj[0], py = gy - sj[1], px = gx - sj[2];
+            const size_t o = ((size_t)pz * win.patch[1] + py) * win.patch[2] + px;
+#pragma unroll
+            for (int c = 0; c < C; ++c) s[c] += pred[((size_t)j * C + c) * pvox + o];
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) accum[c * avox + a] = s[c];
+    }
+}
+
+// number of patch starts along one axis whose trimmed output covers g
+__device__ __forceinline__ int axis_count(int g, int dim, int patch, int overlap, int trim) {
+    const int stride = patch - overlap;
+    const int span = dim - patch + stride;             // range(0, span, stride)
+    if (span <= 0) return 0;
+    const int nstarts = (span + stride - 1) / stride;
+    const int out = patch - 2 * trim;
+    int cnt = 0;
+    int k = (g - trim) / stride;
+    if (g - trim < 0) return 0;
+    if (k > nstarts - 1) k = nstarts - 1;
+    for (; k >= 0; --k) {
+        const int s0 = k * stride + trim;
+        if (s0 + out <= g) break;
+        if (g >= s0 && g < min(s0 + out, dim)) ++cnt;
+    }
+    return cnt;
+}
+
+__global__ __launch_bounds__(256) void finalize_kernel(float* __restrict__ accum, int channels,
+                                                       exaspim_window win, exaspim_block blk) {
+    const size_t avox = (size_t)blk.dims[0] * blk.dims[1] * blk.dims[2];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < avox;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % blk.dims[2]);
+        size_t t = i / blk.dims[2];
+        const int y = (int)(t % blk.dims[1]);
+        const int z = (int)(t / blk.dims[1]);
+        const int cz = axis_count(z + blk.origin[0], blk.global[0], win.patch[0], win.overlap[0], win.trim);
+        const int cy = axis_count(y + blk.origin[1], blk.global[1], win.patch[1], win.overlap[1], win.trim);
+        const int cx = axis_count(x + blk.origin[2], blk.global[2], win.patch[2], win.overlap[2], win.trim);
+        const int cnt = cz * cy * cx;
+        if (cnt > 1) {
+            const float wgt = (float)cnt;
+            for (int c = 0; c < channels; ++c) accum[c * avox + i] = __fdiv_rn(accum[c * avox + i], wgt);
+        }
+    }
+}
+
+static inline unsigned stream_grid(size_t items) {
+    const size_t blocks = (items + 255) / 256;
+    return (unsigned)(blocks < 8192 ? (blocks ? blocks : 1) : 8192);
+}
+
+static int check_block(const exaspim_block* b, const char* who) {
+    EXA_CHECK_ARG(b != nullptr, "%s: NULL block", who);
+    for (int i = 0; i < 3; ++i)
+        EXA_CHECK_ARG(b->dims[i] > 0 && b->global[i] > 0 && b->origin[i] >= 0 &&
+                          b->origin[i] + b->dims[i] <= b->global[i],
+                      "%s: block axis %d: dims %d origin %d global %d", who, i, b->dims[i],
+                      b->origin[i], b->global[i]);
+    return EXASPIM_OK;
+}
+
+static int check_window(const exaspim_window* w, const char* who) {
+    EXA_CHECK_ARG(w != nullptr, "%s: NULL window", who);
+    for (int i = 0; i < 3; ++i)
+        EXA_CHECK_ARG(w->patch[i] > 0 && w->overlap[i] >= 0 && w->overlap[i] < w->patch[i] &&
+                          w->trim >= 0 && 2 * w->trim < w->patch[i],
+                      "%s: window axis %d: patch %d overlap %d trim %d", who, i, w->patch[i],
+                      w->overlap[i], w->trim);
+    return EXASPIM_OK;
+}
+
+}  // namespace exaspim
+
+using namespace exaspim;
+
+extern "C" int exaspim_synth_volume_u16(uint16_t* vol_dev, const exaspim_block* blk,
+                                        uint64_t seed, void* stream) {
+    if (int rc = check_block(blk, "synth")) return rc;
+    EXA_CHECK_ARG(vol_dev != nullptr, "synth: NULL volume");
+    const size_t total = (size_t)blk->dims[0] * blk->dims[1] * blk->dims[2];
+    synth_kernel<<<stream_grid(total), 256, 0, (hipStream_t)stream>>>(vol_dev, *blk, seed);
+    EXA_CHECK_HIP(hipGetLastError());
+    return EXASPIM_OK;
+}
+
+extern "C" int exaspim_histogram(const void* vol_dev, int32_t vox_dtype, size_t n, double clip,
+                                 int32_t has_clip, int32_t pass, uint32_t prefix,
+                                 uint64_t* hist_dev, void* stream) {
+    EXA_CHECK_ARG(vol_dev && hist_dev, "histogram: NULL pointer");
+    EXA_CHECK_ARG(pass == 0 || (pass == 1 && vox_dtype == EXASPIM_VOX_F32),
+                  "histogram: pass %d invalid for voxel dtype %d", pass, vox_dtype);
+    if (n == 0) return EXASPIM_OK;
+    unsigned long long* h = reinterpret_cast<unsigned long long*>(hist_dev);
+    const unsigned grid = (unsigned)((n + 256 * 64 - 1) / (256 * 64) < 2048
+                                         ? ((n + 256 * 64 - 1) / (256 * 64) ? (n + 256 * 64 - 1) / (256 * 64) : 1)
+                                         : 2048);
+    hipStream_t s = (hipStream_t)stream;
+    switch (vox_dtype) {
+        case EXASPIM_VOX_U8:
+            histogram_kernel<EXASPIM_VOX_U8><<<grid, 256, 0, s>>>(vol_dev, n, clip, has_clip, pass, prefix, 0, h);
+            break;
+        case EXASPIM_VOX_U16:
+            histogram_kernel<EXASPIM_VOX_U16><<<grid, 256, 0, s>>>(vol_dev, n, clip, has_clip, pass, prefix, 0, h);
+            break;
+        case EXASPIM_VOX_I16:
+            histogram_kernel<EXASPIM_VOX_I16><<<grid, 256, 0, s>>>(vol_dev, n, clip, has_clip, pass, prefix, 32768 - 4096, h);
+            break;
+        case EXASPIM_VOX_F32:
+            // non-negative floats up to ~1e5 have key halves 0x8000..0xC7C3
+            histogram_kernel<EXASPIM_VOX_F32><<<grid, 256, 0, s>>>(vol_dev, n, clip, has_clip, pass, prefix,
+                                                                 pass == 0 ? 0x8000 + 0x0800 : 0, h);
+            break;
+        default:
+            set_error("histogram: unknown voxel dtype %d", vox_dtype);
+            return EXASPIM_E_INVALID;
+    }
+    EXA_CHECK_HIP(hipGetLastError());
+    return EXASPIM_OK;
+}
+
+extern "C" int exaspim_gather_patches(const void* vol_dev, int32_t vox_dtype,
+                                      const exaspim_block* blk, const int32_t* starts_dev,
+                                      int32_t n, const int32_t patch[3], double clip,
+                                      int32_t has_clip, double mn, double denom, float* out_dev,
+                                      void* stream) {
+    if (int rc = check_block(blk, "gather")) return rc;
+    EXA_CHECK_ARG(vol_dev && starts_dev && out_dev && patch, "gather: NULL pointer");
+    EXA_CHECK_ARG(n > 0 && patch[0] > 0 && patch[1] > 0 && patch[2] > 0, "gather: empty batch");
+    const size_t total = (size_t)patch[0] * patch[1] * patch[2] * n;
+    const unsigned grid = stream_grid(total);
+    hipStream_t s = (hipStream_t)stream;
+#define GATHER(V) gather_kernel<V><<<grid, 256, 0, s>>>(vol_dev, *blk, starts_dev, n, patch[0], patch[1], patch[2], clip, has_clip, mn, denom, out_dev)
+    switch (vox_dtype) {
+        case EXASPIM_VOX_U8: GATHER(EXASPIM_VOX_U8); break;
+        case EXASPIM_VOX_U16: GATHER(EXASPIM_VOX_U16); break;
+        case EXASPIM_VOX_I16: GATHER(EXASPIM_VOX_I16); break;
+        case EXASPIM_VOX_F32: GATHER(EXASPIM_VOX_F32); break;
+        default:
+            set_error("gather: unknown voxel dtype %d", vox_dtype);
+            return EXASPIM_E_INVALID;
+    }
+#undef GATHER
+    EXA_CHECK_HIP(hipGetLastError());
+    return EXASPIM_OK;
+}
+
+extern "C" int exaspim_stitch_accumulate(const float* pred_dev, const int32_t* starts_dev,
+                                         int32_t n, int32_t channels, const exaspim_window* win,
+                                         float* accum_dev, const exaspim_block* blk,
+                                         void* stream) {
+    if (int rc = check_block(blk, "stitch")) return rc;
+    if (int rc = check_window(win, "stitch")) return rc;
+    EXA_CHECK_ARG(pred_dev && starts_dev && accum_dev, "stitch: NULL pointer");
+    EXA_CHECK_ARG(n > 0 && channels >= 1 && channels <= 4, "stitch: n %d channels %d", n, channels);
+    const size_t total = (size_t)(win->patch[0] - 2 * win->trim) * (win->patch[1] - 2 * win->trim) *
+                         (win->patch[2] - 2 * win->trim) * n;
+    const unsigned grid = stream_grid(total);
+    hipStream_t s = (hipStream_t)stream;
+    switch (channels) {
+        case 1: stitch_kernel<1><<<grid, 256, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
+        case 2: stitch_kernel<2><<<grid, 256, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
+        case 3: stitch_kernel<3><<<grid, 256, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
+        case 4: stitch_kernel<4><<<grid, 256, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
+    }
+    EXA_CHECK_HIP(hipGetLastError());
+    return EXASPIM_OK;
+}
+
+extern "C" int exaspim_stitch_finalize(float* accum_dev, int32_t channels,
+                                       const exaspim_window* win, const exaspim_block* blk,
+                                       void* stream) {
+    if (int rc = check_block(blk, "finalize")) return rc;
+    if (int rc = check_window(win, "finalize")) return rc;
+    EXA_CHECK_ARG(accum_dev && channels >= 1, "finalize: bad arguments");
+    const size_t avox = (size_t)blk->dims[0] * blk->dims[1] * blk->dims[2];
+    finalize_kernel<<<stream_grid(avox), 256, 0, (hipStream_t)stream>>>(accum_dev, channels, *win, *blk);
+    EXA_CHECK_HIP(hipGetLastError());
+    return EXASPIM_OK;
+}

@@ -1,0 +1,249 @@
+"""
+MI355X-native stand-in for the reference's ``UNet3D``
+(machine_learning/unet3d.py:16-105 of the reference).
+
+The module tree below exists only to own parameters under the reference's
+state_dict keys (``inc.double_conv.0.weight`` ...), so checkpoints written by
+the reference's trainer (train.py:286) load unchanged with
+``load_state_dict(strict=True)``. No torch operator runs in ``forward``: the
+parameters are BatchNorm-folded and packed once by the C-ABI extension, and
+the whole network (3x3x3 convs on the matrix cores, max-pool, trilinear
+upsampling, skip concatenation, 1x1x1 head) executes as hand-written gfx950
+kernels on the caller's HIP stream (csrc/engine.hip).
+
+Inference only (eval-mode BatchNorm, ``trilinear=True``); there is no CPU
+path -- calling the model with a CPU tensor raises.
+"""
+
+import ctypes
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from aind_exaspim_neuron_segmentation_amd import _native
+from aind_exaspim_neuron_segmentation_amd.machine_learning.spec import (
+    unet_channels,
+    unet_layer_specs,
+)
+
+
+class _Holder(nn.Module):
+    """Anonymous node of the parameter tree (no computation of its own)."""
+
+
+class _ConvParams(nn.Module):
+    """Weight and bias of one convolution, initialised like nn.Conv3d."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k, k))
+        self.bias = nn.Parameter(torch.empty(cout))
+        bound = 1.0 / math.sqrt(cin * k ** 3)
+        nn.init.uniform_(self.weight, -bound, bound)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class _NormParams(nn.Module):
+    """Affine parameters and running statistics of one BatchNorm3d."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+def _attach(root, dotted, module):
+    """Registers "module" under a dotted path, creating holders on the way."""
+    node = root
+    parts = dotted.split(".")
+    for name in parts[:-1]:
+        if name not in node._modules:
+            node.add_module(name, _Holder())
+        node = node._modules[name]
+    node.add_module(parts[-1], module)
+
+
+class UNet3D(nn.Module):
+    """
+    3D U-Net whose forward pass runs on the exaspim_affinity HIP extension.
+
+    Parameters
+    ----------
+    output_channels : int, optional
+        Number of channels in the output. Default is 1.
+    trilinear : bool, optional
+        Must be True (the only variant load_model of the reference creates).
+    width_multiplier : float, optional
+        Factor that scales the number of channels in each layer. Default is 1.
+    compute_dtype : str, optional
+        "fp32" (exact fp32 matrix-core path, default), "bf16" or "fp16"
+        (16-bit activations and weights, fp32 accumulation).
+    """
+
+    def __init__(self, output_channels=1, trilinear=True, width_multiplier=1,
+                 compute_dtype="fp32"):
+        super().__init__()
+        if compute_dtype not in _native.DTYPE_CODES:
+            raise ValueError(f"unknown compute_dtype {compute_dtype!r}")
+        self.channels = unet_channels(width_multiplier)
+        self.trilinear = trilinear
+        self.output_channels = output_channels
+        self.compute_dtype = compute_dtype
+        blocks, (head_in, head_out) = unet_layer_specs(
+            output_channels, trilinear, width_multiplier
+        )
+        for prefix, cin, cmid, cout in blocks:
+            _attach(self, f"{prefix}.0", _ConvParams(cin, cmid, 3))
+            _attach(self, f"{prefix}.1", _NormParams(cmid))
+            _attach(self, f"{prefix}.3", _ConvParams(cmid, cout, 3))
+            _attach(self, f"{prefix}.4", _NormParams(cout))
+        _attach(self, "outc.conv", _ConvParams(head_in, head_out, 1))
+        self._engine = None       # opaque exaspim_unet*
+        self._engine_key = None
+        self._packed = None       # device image of the packed weights
+        self._workspace = None
+
+    # ---- engine management -------------------------------------------------
+    def _canonical_params(self):
+        """float32 vector in the order exaspim_unet_param_count documents."""
+        chunks = []
+        for key, value in self.state_dict().items():
+            if key.endswith("num_batches_tracked"):
+                continue
+            chunks.append(value.detach().to("cpu", torch.float32).reshape(-1))
+        return torch.cat(chunks).contiguous().numpy()
+
+    def _state_key(self, device):
+        tensors = list(self.parameters()) + list(self.buffers())
+        return (
+            str(device), self.compute_dtype,
+            tuple((t.data_ptr(), t._version) for t in tensors),
+        )
+
+    def _release_engine(self):
+        if self._engine is not None:
+            _native.lib().exaspim_unet_destroy(self._engine)
+        self._engine = None
+        self._engine_key = None
+
+    def __del__(self):
+        try:
+            self._release_engine()
+        except Exception:
+            pass
+
+    def _ensure_engine(self, device):
+        key = self._state_key(device)
+        if self._engine is not None and key == self._engine_key:
+            return
+        self._release_engine()
+        lib = _native.lib()
+        ch = _native.channels_array(self.channels)
+        code = _native.DTYPE_CODES[self.compute_dtype]
+        params = self._canonical_params()
+        expected = lib.exaspim_unet_param_count(ch, self.output_channels)
+        if expected == 0:
+            raise ValueError(f"unsupported network: {_native.last_error()}")
+        if params.size != expected:
+            raise RuntimeError(
+                f"parameter vector has {params.size} values, extension expects {expected}"
+            )
+        nbytes = lib.exaspim_unet_packed_bytes(ch, self.output_channels, code)
+        packed = np.empty(nbytes, dtype=np.uint8)
+        _native.check(
+            lib.exaspim_unet_pack_weights(
+                ch, self.output_channels, code, params.ctypes.data, params.size,
+                packed.ctypes.data, nbytes,
+            ),
+            "exaspim_unet_pack_weights",
+        )
+        self._packed = torch.from_numpy(packed).to(device)
+        handle = ctypes.c_void_p()
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        _native.check(
+            lib.exaspim_unet_create(
+                ch, self.output_channels, code, index, self._packed.data_ptr(), nbytes,
+                ctypes.byref(handle),
+            ),
+            "exaspim_unet_create",
+        )
+        self._engine = handle
+        self._engine_key = key
+
+    def _get_workspace(self, n, d, h, w, device):
+        need = _native.lib().exaspim_unet_workspace_bytes(self._engine, n, d, h, w)
+        if need == 0:
+            raise RuntimeError(
+                "Sizes of tensors must match: " + _native.last_error()
+            )
+        ws = self._workspace
+        if ws is None or ws.numel() < need or ws.device != device:
+            self._workspace = None
+            ws = torch.empty(need, dtype=torch.uint8, device=device)
+            self._workspace = ws
+        return ws
+
+    # ---- forward -----------------------------------------------------------
+    def run(self, x, apply_sigmoid=False, out=None):
+        """
+        Runs the network on a float32 device tensor of shape (B, 1, D, H, W).
+
+        Parameters
+        ----------
+        x : torch.Tensor
+            Input patches on a HIP device.
+        apply_sigmoid : bool, optional
+            Fuse the sigmoid of inference.py:158 into the head. Default False.
+        out : torch.Tensor, optional
+            Preallocated (B, C, D, H, W) float32 output.
+
+        Returns
+        -------
+        torch.Tensor
+            Logits (or probabilities) with shape (B, output_channels, D, H, W).
+        """
+        if self.training:
+            raise RuntimeError(
+                "UNet3D (MI355X) implements eval-mode inference only; call .eval()"
+            )
+        if not x.is_cuda:
+            raise RuntimeError(
+                "UNet3D (MI355X) has no CPU path: move the input to a HIP device"
+            )
+        if x.dim() != 5 or x.shape[1] != 1:
+            raise RuntimeError(f"expected input of shape (B, 1, D, H, W), got {tuple(x.shape)}")
+        x = x.to(torch.float32).contiguous()
+        n, _, d, h, w = x.shape
+        if d % 16 or h % 16 or w % 16:
+            raise RuntimeError(
+                "Sizes of tensors must match: patch dimensions must be multiples of 16, "
+                f"got {(d, h, w)}"
+            )
+        device = x.device
+        with torch.cuda.device(device):
+            self._ensure_engine(device)
+            ws = self._get_workspace(n, d, h, w, device)
+            if out is None:
+                out = torch.empty(
+                    (n, self.output_channels, d, h, w), dtype=torch.float32, device=device
+                )
+            stream = torch.cuda.current_stream(device).cuda_stream
+            _native.check(
+                _native.lib().exaspim_unet_forward(
+                    self._engine, x.data_ptr(), out.data_ptr(), n, d, h, w,
+                    1 if apply_sigmoid else 0, ws.data_ptr(), ws.numel(), stream,
+                ),
+                "exaspim_unet_forward",
+            )
+        return out
+
+    def forward(self, x):
+        """
+        Forward pass: (B, 1, D, H, W) -> logits (B, output_channels, D, H, W).
+        """
+        return self.run(x, apply_sigmoid=False)

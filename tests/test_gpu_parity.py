@@ -1,0 +1,273 @@
+"""
+GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through
+the C ABI, against the CPU oracle on the same seeded inputs and against the
+golden vectors produced by the reference itself.
+
+Tolerances: integer / index / byte work (percentiles, gather, stitch) is
+bit-exact; the fp32 network path is held to 1e-4 abs on logits and 1e-5 abs on
+probabilities (north_star allows 1e-3); bf16 / fp16 paths are reported and
+held to the tolerance written next to each assertion.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from aind_exaspim_neuron_segmentation_amd.utils import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import reference_path
+
+    return reference_path
+
+
+def make_model(dev, out_channels=3, seed=1, compute_dtype="fp32"):
+    from aind_exaspim_neuron_segmentation_amd.machine_learning.unet3d import UNet3D
+
+    sd = synthetic.synth_state_dict(out_channels, 1, seed=seed)
+    model = UNet3D(output_channels=out_channels, compute_dtype=compute_dtype)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    return model.to(dev).eval(), sd
+
+
+def normalized_input(oracle, shape, seed, n=1):
+    vols = [synthetic.synth_volume(shape, seed=seed + i) for i in range(n)]
+    x = np.stack([oracle.normalize(np.minimum(v, 1000)) for v in vols])[:, None]
+    return torch.tensor(x.astype(np.float32))
+
+
+# ---------------------------------------------------------------- network ---
+@pytest.mark.parametrize("shape", [(32, 32, 32), (16, 48, 64), (48, 32, 16)])
+def test_unet_logits_fp32_vs_oracle(dev, oracle, shape):
+    model, sd = make_model(dev)
+    x = normalized_input(oracle, shape, seed=40, n=2)
+    want = oracle.unet_forward(x, oracle.OracleModel(sd).sd).numpy()
+    got = model(x.to(dev)).cpu().numpy()
+    assert got.shape == want.shape
+    err = np.abs(got - want).max()
+    print(f"fp32 logits {shape}: max|diff| = {err:.3e}")
+    assert err < 1e-4
+
+
+def test_unet_single_96_patch_vs_reference_golden(dev, oracle, golden):
+    g = golden("g4_single_patch.npz")
+    model, _ = make_model(dev)
+    x = normalized_input(oracle, (96, 96, 96), seed=0)
+    logits = model(x.to(dev))
+    got = logits.cpu().numpy()[0]
+    err = np.abs(got[:, ::8, ::8, ::8] - g["logits_sub"]).max()
+    err2 = np.abs(got[:, 40:44, 17:21, :] - g["logits_slab"]).max()
+    print(f"fp32 96^3 logits vs reference: {err:.3e} / {err2:.3e}")
+    assert err < 1e-4 and err2 < 1e-4
+    sig = torch.sigmoid(logits).cpu().numpy()[0, :, ::8, ::8, ::8]
+    assert np.abs(sig - g["sigmoid_sub"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("cdt,tol", [("bf16", 2e-2), ("fp16", 2e-3)])
+def test_unet_16bit_paths_vs_oracle(dev, oracle, cdt, tol):
+    # 16-bit storage of activations/weights, fp32 accumulate: tolerance on the
+    # probabilities, stated per dtype (bf16 has 8 significant bits).
+    model, sd = make_model(dev, compute_dtype=cdt)
+    x = normalized_input(oracle, (32, 32, 32), seed=41, n=2)
+    want = torch.sigmoid(oracle.unet_forward(x, oracle.OracleModel(sd).sd)).numpy()
+    got = model.run(x.to(dev), apply_sigmoid=True).cpu().numpy()
+    err = np.abs(got - want)
+    print(f"{cdt} probabilities: max {err.max():.3e} mean {err.mean():.3e}")
+    assert err.max() < tol
+
+
+def test_unet_rejects_bad_inputs(dev):
+    model, _ = make_model(dev)
+    with pytest.raises(RuntimeError, match="Sizes of tensors must match"):
+        model(torch.zeros(1, 1, 24, 32, 32, device=dev))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        model(torch.zeros(1, 1, 32, 32, 32))
+    model.train()
+    with pytest.raises(RuntimeError, match="eval"):
+        model(torch.zeros(1, 1, 32, 32, 32, device=dev))
+
+
+def test_engine_repacks_after_load_state_dict(dev, oracle):
+    model, _ = make_model(dev, seed=1)
+    x = normalized_input(oracle, (16, 16, 16), seed=5).to(dev)
+    a = model(x).cpu().numpy()
+    sd2 = synthetic.synth_state_dict(3, 1, seed=9)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd2.items()})
+    b = model(x).cpu().numpy()
+    want = oracle.unet_forward(x.cpu(), oracle.OracleModel(sd2).sd).numpy()
+    assert np.abs(a - b).max() > 1e-3
+    assert np.abs(b - want).max() < 1e-4
+
+
+# ---------------------------------------------------------- pre-processing ---
+def _volumes():
+    vol = synthetic.synth_volume((40, 48, 56), seed=3)
+    return {
+        "u16": vol,
+        "u16_sparse": np.where(vol > 1990, vol * 20, vol // 50).astype(np.uint16),
+        "f32": (vol.astype(np.float32) * 0.37 - 50.0),
+        "u8": (vol % 251).astype(np.uint8),
+        "i16": (vol.astype(np.int32) - 1000).astype(np.int16),
+        "const": np.full((8, 8, 8), 7, dtype=np.uint16),
+    }
+
+
+@pytest.mark.parametrize("name", list(_volumes()))
+@pytest.mark.parametrize("clip,pct", [(1000, (1, 99.9)), (None, (0.5, 75.25)), (300, (0, 100))])
+def test_percentiles_bit_exact(dev, name, clip, pct):
+    from aind_exaspim_neuron_segmentation_amd import inference
+
+    arr = _volumes()[name]
+    ref = np.minimum(arr, clip) if clip is not None else arr
+    want = np.percentile(ref, pct)
+    vol = inference.DeviceVolume.from_array(arr, dev)
+    mn, mx = inference.volume_percentiles(vol, clip, pct)
+    assert (mn, mx) == (want[0], want[1])
+
+
+@pytest.mark.parametrize("name", ["u16", "f32", "i16", "u8"])
+def test_gather_bit_exact(dev, oracle, name):
+    from aind_exaspim_neuron_segmentation_amd import inference
+
+    arr = _volumes()[name]  # (40, 48, 56)
+    patch, overlap = (32, 32, 48), (8, 4, 40)
+    clipped = np.minimum(arr, 1000)
+    mn, mx = np.percentile(clipped, (1, 99.9))
+    img = oracle.normalize(clipped)[None, None]
+    starts = list(oracle.generate_patch_starts(img.shape, patch, overlap))
+    assert len(starts) > 4
+    want = oracle.get_batch_inputs(img, starts, patch).numpy()
+    vol = inference.DeviceVolume.from_array(arr, dev)
+    sdev = torch.tensor(starts, dtype=torch.int32, device=dev)
+    got = inference._get_batch_inputs(vol, sdev, patch, dev, clip=1000, mn=mn, mx=mx)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def test_gather_multi_reflection_and_singleton(dev, oracle):
+    from aind_exaspim_neuron_segmentation_amd import inference
+
+    arr = synthetic.synth_volume((33, 17, 1), seed=8)
+    patch = (96, 32, 4)
+    img = arr.astype(np.float64)[None, None]
+    want = oracle.get_batch_inputs(img, [(0, 0, 0)], patch).numpy()
+    vol = inference.DeviceVolume.from_array(arr, dev)
+    sdev = torch.zeros((1, 3), dtype=torch.int32, device=dev)
+    # mn = 0 and denom = 4096 keep every voxel value (< 2000) distinct and exact
+    got = inference._get_batch_inputs(vol, sdev, patch, dev, clip=None, mn=0.0, mx=4096.0 - 1e-8)
+    np.testing.assert_array_equal(got.cpu().numpy(), (want / 4096.0).astype(np.float32))
+
+
+# --------------------------------------------------------- post-processing ---
+@pytest.mark.parametrize("trim,channels", [(4, 3), (0, 1), (2, 2)])
+def test_stitch_bit_exact(dev, trim, channels):
+    from aind_exaspim_neuron_segmentation_amd import inference
+
+    shape, patch, overlap = (56, 40, 48), (32, 32, 32), (8, 8, 8)
+    plan = inference.SlidingWindow(shape, patch, overlap, trim)
+    starts = plan.starts()
+    rng = np.random.default_rng(0)
+    preds = rng.random((len(starts), channels) + patch, dtype=np.float32)
+    accum = np.zeros((channels,) + shape, np.float32)
+    wgt = np.zeros(shape, np.float16)
+    o = [p - 2 * trim for p in patch]
+    for p, s in zip(preds, starts):
+        s0 = [si + trim for si in s]
+        e = [min(a + b, d) for a, b, d in zip(s0, o, shape)]
+        sl = tuple(slice(a, b) for a, b in zip(s0, e))
+        ps = tuple(slice(trim, trim + b - a) for a, b in zip(s0, e))
+        accum[(slice(None),) + sl] += p[(slice(None),) + ps]
+        wgt[sl] += 1
+    np.divide(accum, wgt, out=accum, where=wgt != 0)
+
+    block = inference._native.Block.make(shape)
+    acc_dev = torch.zeros((channels,) + shape, dtype=torch.float32, device=dev)
+    sdev = torch.tensor(starts, dtype=torch.int32, device=dev)
+    pdev = torch.tensor(preds, device=dev)
+    for i in range(0, len(starts), 5):
+        inference.stitch_accumulate(pdev[i:i + 5].contiguous(), sdev[i:i + 5], plan, acc_dev, block)
+    inference.stitch_finalize(acc_dev, plan, block)
+    np.testing.assert_array_equal(acc_dev.cpu().numpy(), accum)
+
+
+# --------------------------------------------------------------- end to end ---
+def test_predict_fp32_vs_reference_golden_and_oracle(dev, oracle, golden):
+    from aind_exaspim_neuron_segmentation_amd import inference
+
+    g = golden("g5_fullwidth_small.npz")
+    vol = synthetic.synth_volume((72, 40, 56), seed=11)
+    model, sd = make_model(dev)
+    kw = dict(batch_size=4, patch_shape=(32, 32, 32), overlap=(8, 8, 8), trim=4)
+    got = inference.predict(vol, model, verbose=False, **kw)
+    assert got.dtype == np.float32 and got.shape == (3, 72, 40, 56)
+    err_ref = np.abs(got[:, ::2, ::2, ::2] - g["pred"]).max()
+    want = oracle.predict(vol, oracle.OracleModel(sd), **kw)
+    err = np.abs(got - want).max()
+    print(f"predict fp32: vs reference golden {err_ref:.3e}, vs oracle {err:.3e}")
+    assert err_ref < 1e-5 and err < 1e-5
+    np.testing.assert_array_equal(got == 0, want == 0)  # uncovered border stays exactly 0
+
+    model1, sd1 = make_model(dev, out_channels=1, seed=4)
+    kw1 = dict(batch_size=5, patch_shape=(32, 32, 32), overlap=(16, 16, 16), trim=2)
+    got1 = inference.predict(vol, model1, affinity_mode=False, verbose=False, **kw1)
+    assert got1.shape == (72, 40, 56)
+    assert np.abs(got1[::2, ::2, ::2] - g["pred_fg"]).max() < 1e-5
+
+
+def test_predict_default_config_160_vs_reference_golden(dev, golden):
+    from aind_exaspim_neuron_segmentation_amd import inference
+
+    g = golden("g6_default_160.npz")
+    vol = synthetic.synth_volume((160, 160, 160), seed=0)
+    model, _ = make_model(dev)
+    got = inference.predict(vol, model, batch_size=8, verbose=False)
+    err = np.abs(got[:, ::5, ::5, ::5] - g["pred_sub"]).max()
+    print(f"predict 160^3 defaults vs reference: {err:.3e}")
+    assert err < 1e-5
+    assert np.abs(got[:, 80, 81, :] - g["pred_line"]).max() < 1e-5
+    zero = (got == 0).all(axis=0)
+    assert abs(zero.mean() - float(g["zero_fraction"])) < 1e-12
+    np.testing.assert_array_equal(zero.all(axis=(1, 2)), g["zero_z"])
+    # determinism: the stitch has no atomics
+    again = inference.predict(vol, model, batch_size=8, verbose=False)
+    np.testing.assert_array_equal(got, again)
+
+
+def test_predict_input_variants(dev, oracle):
+    from aind_exaspim_neuron_segmentation_amd import inference
+
+    model, sd = make_model(dev)
+    vol = synthetic.synth_volume((40, 48, 40), seed=13)
+    kw = dict(batch_size=2, patch_shape=(32, 32, 32), overlap=(8, 8, 8), trim=0,
+              brightness_clip=400, normalization_percentiles=(5, 95))
+    volf = (vol.astype(np.float32) * 0.5)[None, None]
+    want = oracle.predict(volf, oracle.OracleModel(sd), **kw)
+    got = inference.predict(volf, model, verbose=False, **kw)
+    assert np.abs(got - want).max() < 1e-5
+    # volume smaller than the overlap on one axis -> no patches -> zeros
+    tiny = synthetic.synth_volume((8, 48, 40), seed=1)
+    out = inference.predict(tiny, model, verbose=False, **kw)
+    assert out.shape == (3, 8, 48, 40) and not out.any()
+    with pytest.raises(RuntimeError, match="multiples of 16"):
+        inference.predict(vol, model, patch_shape=(24, 32, 32), overlap=(8, 8, 8), verbose=False)
+
+
+def test_synth_volume_matches_numpy(dev):
+    from aind_exaspim_neuron_segmentation_amd import _native
+
+    shape, origin, gshape = (5, 7, 9), (3, 2, 1), (16, 12, 10)
+    t = torch.empty(shape, dtype=torch.int16, device=dev)
+    blk = _native.Block.make(shape, origin, gshape)
+    _native.check(_native.lib().exaspim_synth_volume_u16(t.data_ptr(), blk, 5, None), "synth")
+    want = synthetic.synth_volume(shape, seed=5, origin=origin, global_shape=gshape)
+    np.testing.assert_array_equal(t.cpu().numpy().view(np.uint16), want)

@@ -1,0 +1,213 @@
+"""
+CPU-only checks of the C-ABI library and the host logic around it: the shared
+object loads without a GPU, exports every symbol the header declares, packs
+weights (BatchNorm folding + MFMA fragment order) correctly, and refuses to
+compute without a device.
+"""
+
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from aind_exaspim_neuron_segmentation_amd import _native
+from aind_exaspim_neuron_segmentation_amd.utils import img_util, synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_native.LIB_PATH):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    return _native.lib()
+
+
+def test_header_symbols_are_exported(lib):
+    header = open(os.path.join(ROOT, "include", "exaspim_affinity.h")).read()
+    declared = set(re.findall(r"\b(exaspim_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.exaspim_abi_version() == 1
+
+
+def test_param_count_matches_state_dict(lib):
+    sd = synthetic.synth_state_dict(3, 1, seed=1)
+    n = sum(v.size for k, v in sd.items() if not k.endswith("num_batches_tracked"))
+    ch = _native.channels_array([32, 64, 128, 256, 512])
+    assert lib.exaspim_unet_param_count(ch, 3) == n == 12951267
+    assert lib.exaspim_unet_param_count(_native.channels_array([4, 8, 16, 32, 64]), 1) > 0
+    # invalid widths are rejected with a message
+    assert lib.exaspim_unet_param_count(_native.channels_array([32, 64, 128, 256, 500]), 3) == 0
+    assert "channels" in _native.last_error()
+
+
+def _flat_params(sd):
+    return np.concatenate(
+        [v.reshape(-1).astype(np.float32) for k, v in sd.items()
+         if not k.endswith("num_batches_tracked")]
+    )
+
+
+@pytest.mark.parametrize("dtype,code", [("f32", 0), ("bf16", 1), ("f16", 2)])
+def test_pack_weights_folds_batchnorm_in_fragment_order(lib, dtype, code):
+    widths = [4, 8, 16, 32, 64]  # exercises channel padding to 32
+    sd = synthetic.synth_state_dict(3, 0.125, seed=3)
+    params = _flat_params(sd)
+    ch = _native.channels_array(widths)
+    assert lib.exaspim_unet_param_count(ch, 3) == params.size
+    nbytes = lib.exaspim_unet_packed_bytes(ch, 3, code)
+    packed = np.zeros(nbytes, np.uint8)
+    rc = lib.exaspim_unet_pack_weights(ch, 3, code, params.ctypes.data, params.size,
+                                       packed.ctypes.data, nbytes)
+    _native.check(rc, "pack")
+
+    # inc.0 block: float32 [27][32] folded weights then bias (256-byte aligned)
+    w = sd["inc.double_conv.0.weight"].astype(np.float64).reshape(4, 27)
+    b = sd["inc.double_conv.0.bias"].astype(np.float64)
+    g = sd["inc.double_conv.1.weight"].astype(np.float64)
+    beta = sd["inc.double_conv.1.bias"].astype(np.float64)
+    mu = sd["inc.double_conv.1.running_mean"].astype(np.float64)
+    var = sd["inc.double_conv.1.running_var"].astype(np.float64)
+    s = g / np.sqrt(var + 1e-5)
+    first_w = packed[: 27 * 32 * 4].view(np.float32).reshape(27, 32)
+    np.testing.assert_array_equal(first_w[:, :4], (w * s[:, None]).T.astype(np.float32))
+    assert not first_w[:, 4:].any()
+    off_b = (27 * 32 * 4 + 255) // 256 * 256
+    first_b = packed[off_b: off_b + 32 * 4].view(np.float32)
+    np.testing.assert_array_equal(first_b[:4], ((b - mu) * s + beta).astype(np.float32))
+
+    # inc.3 block (4 -> 4 channels, padded to 32 -> 32): check fragment order
+    off_w = off_b + 256
+    es = 4 if code == 0 else 2
+    G = 16 // es
+    KC = 2 * G
+    nchunks = 32 // KC
+    w3 = sd["inc.double_conv.3.weight"].astype(np.float64).reshape(4, 4, 27)
+    s3 = sd["inc.double_conv.4.weight"].astype(np.float64) / np.sqrt(
+        sd["inc.double_conv.4.running_var"].astype(np.float64) + 1e-5)
+    raw = packed[off_w: off_w + 27 * 32 * 32 * es]
+    if code == 0:
+        vals = raw.view(np.float32).astype(np.float64)
+    elif code == 1:
+        vals = (raw.view(np.uint16).astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    else:
+        vals = raw.view(np.float16).astype(np.float64)
+    frag = vals.reshape(nchunks, 27, 1, 64, G)
+    tol = {0: 0.0, 1: 2 ** -8, 2: 2 ** -10}[code]
+    for c in range(nchunks):
+        for lane in (0, 3, 31, 32, 35, 63):
+            for j in range(G):
+                ci = KC * c + G * (lane >> 5) + j
+                co = lane & 31
+                for t in (0, 13, 26):
+                    want = w3[co, ci, t] * s3[co] if (ci < 4 and co < 4) else 0.0
+                    got = frag[c, t, 0, lane, j]
+                    if code == 0:
+                        assert got == np.float32(want)
+                    else:
+                        assert abs(got - want) <= tol * abs(want) + 1e-30
+
+
+def test_pack_rejects_wrong_sizes(lib):
+    ch = _native.channels_array([32, 64, 128, 256, 512])
+    buf = np.zeros(16, np.float32)
+    rc = lib.exaspim_unet_pack_weights(ch, 3, 0, buf.ctypes.data, 16, buf.ctypes.data, 64)
+    assert rc == -1 and "parameters" in _native.last_error()
+    with pytest.raises(ValueError):
+        _native.check(rc, "pack")
+
+
+def test_create_without_device_fails_loudly(lib):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    ch = _native.channels_array([32, 64, 128, 256, 512])
+    nbytes = lib.exaspim_unet_packed_bytes(ch, 3, 0)
+    handle = ctypes.c_void_p()
+    fake = ctypes.c_void_p(0x1000)
+    rc = lib.exaspim_unet_create(ch, 3, 0, 0, fake, nbytes, ctypes.byref(handle))
+    assert rc == -4 and "device" in _native.last_error()
+
+
+def test_model_refuses_cpu_tensors():
+    import torch
+
+    from aind_exaspim_neuron_segmentation_amd import inference
+    from aind_exaspim_neuron_segmentation_amd.machine_learning.unet3d import UNet3D
+
+    model = UNet3D(output_channels=3).eval()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        model(torch.zeros(1, 1, 16, 16, 16))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        inference.predict(np.zeros((40, 40, 40), np.uint16), model, verbose=False)
+
+
+def test_state_dict_keys_match_reference_layout():
+    from aind_exaspim_neuron_segmentation_amd.machine_learning.unet3d import UNet3D
+
+    model = UNet3D(output_channels=3)
+    sd = synthetic.synth_state_dict(3, 1, seed=1)
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    assert len(sd) == 128
+    for k, v in model.state_dict().items():
+        assert tuple(v.shape) == sd[k].shape, k
+    assert sum(p.numel() for p in model.parameters()) == 12946851
+
+
+def test_patch_helpers_match_golden(golden):
+    from aind_exaspim_neuron_segmentation_amd import inference
+
+    g = golden("g1_patch_starts.npz")
+    for i in range(int(g["n_cases"])):
+        vol = tuple(int(v) for v in g[f"case{i}_vol"])
+        ps = tuple(int(v) for v in g[f"case{i}_patch"])
+        ov = tuple(int(v) for v in g[f"case{i}_overlap"])
+        shape5 = (1, 1) + vol
+        assert inference.count_patches(shape5, ps, ov) == int(g[f"case{i}_count"])
+        starts = np.array(list(inference.generate_patch_starts(shape5, ps, ov)),
+                          dtype=np.int64).reshape(-1, 3)
+        if vol == (512, 512, 512):
+            starts = starts[[0, 1, 7, 8, 63, 64, 510, 511]]
+        np.testing.assert_array_equal(starts, g[f"case{i}_starts"])
+    with pytest.raises(AssertionError):
+        inference.count_patches((96, 96, 96), (96,) * 3, (32,) * 3)
+    sl = img_util.get_patch_slices((64, 0, 128), (96, 96, 96), (130, 50, 224))
+    g2 = golden("g2b_padding.npz")
+    np.testing.assert_array_equal(np.array([[s.start, s.stop] for s in sl]), g2["slices"])
+
+
+def test_percentiles_from_histogram_match_numpy(golden):
+    g = golden("g2_normalize.npz")
+    vol = synthetic.synth_volume((40, 48, 56), seed=3)
+    cases = {
+        "u16_clip1000": np.minimum(vol, 1000),
+        "u16_noclip": vol,
+        "u8": (vol % 251).astype(np.uint8),
+        "i16": (vol.astype(np.int32) - 1000).astype(np.int16),
+        "const": np.full((8, 8, 8), 7, dtype=np.uint16),
+    }
+    for name, arr in cases.items():
+        offset = 32768 if arr.dtype == np.int16 else 0
+        hist = np.bincount(arr.astype(np.int64).ravel() + offset, minlength=65536)
+        stats = img_util.OrderStatistics(hist, lambda b, d=arr.dtype, o=offset: d.type(b - o))
+        for pct_name, pct in (("default", (1, 99.9)), ("alt", (0.5, 75.25))):
+            got = img_util.percentiles_from_statistics(stats, pct, arr.dtype)
+            np.testing.assert_array_equal(got, g[f"{name}_{pct_name}_mnmx"])
+
+
+def test_reflect_index_matches_numpy_pad():
+    for n in (1, 2, 3, 17, 33):
+        for p in (0, 1, n - 1, n, 2 * n + 3, 63):
+            if p < 0:
+                continue
+            a = np.arange(n)
+            want = np.pad(a, (0, p), mode="reflect")
+            got = [img_util.reflect_index(j, n) for j in range(n + p)]
+            np.testing.assert_array_equal(got, want)
