@@ -78,6 +78,9 @@ SIGNATURES = {
     "exaspim_unet_destroy": (None, [_vp]),
     "exaspim_unet_workspace_bytes": (_sz, [_vp, _i32, _i32, _i32, _i32]),
     "exaspim_unet_forward": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "exaspim_unet_timing_begin": (_i32, [_vp, ctypes.c_uint32]),
+    "exaspim_unet_timing_read": (_i32, [_vp, ctypes.POINTER(ctypes.c_double * 17),
+                                        ctypes.POINTER(ctypes.c_int32 * 17)]),
     "exaspim_histogram": (_i32, [_vp, _i32, _sz, ctypes.c_double, _i32, _i32, ctypes.c_uint32, _vp, _vp]),
     "exaspim_gather_patches": (_i32, [_vp, _i32, ctypes.POINTER(Block), _vp, _i32, _I32x3,
                                       ctypes.c_double, _i32, ctypes.c_double, ctypes.c_double, _vp, _vp]),

@@ -22,10 +22,23 @@ struct Workspace {
 
 }  // namespace exaspim
 
+// Optional per-layer timing with HIP events recorded on the launch stream
+// (exaspim_unet_timing_*): a ring of event pairs around the MFMA convolutions
+// selected by a layer mask.
+struct LayerTimer {
+    static constexpr int kRing = 4096;
+    uint32_t mask = 0;
+    int next = 0, used = 0;
+    hipEvent_t start[kRing], stop[kRing];
+    int layer[kRing];
+    bool created = false;
+};
+
 struct exaspim_unet {
     exaspim::UNetPlan plan;
     int device;
     const char* packed;  // device image (caller-owned)
+    LayerTimer* timer = nullptr;
 };
 
 namespace exaspim {
@@ -86,7 +99,21 @@ static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, in
         a.dst = dst; a.cout = L.cout;
         a.n = n; a.d = d >> l; a.h = h >> l; a.w = w >> l;
         a.slope = kLeakySlope;
-        return launch_conv3x3x3(dt, a, stream);
+        LayerTimer* t = e->timer;
+        const bool timed = t && (t->mask >> idx & 1u) && t->used < LayerTimer::kRing;
+        int slot = 0;
+        if (timed) {
+            slot = t->next;
+            EXA_CHECK_HIP(hipEventRecord(t->start[slot], stream));
+        }
+        const int r = launch_conv3x3x3(dt, a, stream);
+        if (timed && r == EXASPIM_OK) {
+            EXA_CHECK_HIP(hipEventRecord(t->stop[slot], stream));
+            t->layer[slot] = idx;
+            t->next = (slot + 1) % LayerTimer::kRing;
+            t->used++;
+        }
+        return r;
     };
 #define RUN(expr) do { rc = (expr); if (rc) return rc; } while (0)
 
@@ -183,7 +210,53 @@ extern "C" int exaspim_unet_create(const int32_t channels[5], int32_t out_channe
     return EXASPIM_OK;
 }
 
-extern "C" void exaspim_unet_destroy(exaspim_unet* h) { delete h; }
+extern "C" void exaspim_unet_destroy(exaspim_unet* h) {
+    if (!h) return;
+    if (h->timer) {
+        if (h->timer->created)
+            for (int i = 0; i < LayerTimer::kRing; ++i) {
+                (void)hipEventDestroy(h->timer->start[i]);
+                (void)hipEventDestroy(h->timer->stop[i]);
+            }
+        delete h->timer;
+    }
+    delete h;
+}
+
+extern "C" int exaspim_unet_timing_begin(exaspim_unet* h, uint32_t conv_mask) {
+    EXA_CHECK_ARG(h != nullptr, "timing_begin: NULL handle");
+    if (!h->timer) h->timer = new (std::nothrow) LayerTimer;
+    EXA_CHECK_ARG(h->timer != nullptr, "timing_begin: out of host memory");
+    LayerTimer* t = h->timer;
+    if (!t->created) {
+        for (int i = 0; i < LayerTimer::kRing; ++i) {
+            EXA_CHECK_HIP(hipEventCreate(&t->start[i]));
+            EXA_CHECK_HIP(hipEventCreate(&t->stop[i]));
+        }
+        t->created = true;
+    }
+    t->mask = conv_mask;
+    t->next = 0;
+    t->used = 0;
+    return EXASPIM_OK;
+}
+
+extern "C" int exaspim_unet_timing_read(exaspim_unet* h, double ms_sum[17], int32_t count[17]) {
+    EXA_CHECK_ARG(h && h->timer && ms_sum && count, "timing_read: timing was not started");
+    LayerTimer* t = h->timer;
+    for (int i = 0; i < kNumMfmaConvs; ++i) { ms_sum[i] = 0.0; count[i] = 0; }
+    for (int s = 0; s < t->used; ++s) {
+        EXA_CHECK_HIP(hipEventSynchronize(t->stop[s]));
+        float ms = 0.f;
+        EXA_CHECK_HIP(hipEventElapsedTime(&ms, t->start[s], t->stop[s]));
+        ms_sum[t->layer[s]] += ms;
+        count[t->layer[s]]++;
+    }
+    t->mask = 0;
+    t->used = 0;
+    t->next = 0;
+    return EXASPIM_OK;
+}
 
 extern "C" size_t exaspim_unet_workspace_bytes(const exaspim_unet* h, int32_t n, int32_t d,
                                                int32_t hgt, int32_t w) {

@@ -118,6 +118,15 @@ int exaspim_unet_forward(exaspim_unet* h, const float* x_dev, float* out_dev,
                          int32_t apply_sigmoid, void* workspace_dev,
                          size_t workspace_bytes, void* stream);
 
+/* Measurement hooks (bench.py's roofline leg). timing_begin arms HIP-event
+ * timing, on the launch stream, of the MFMA convolutions whose bit is set in
+ * conv_mask (bit i = i-th 3x3x3 conv after inc.0 in state_dict order: inc.3,
+ * down1.0, down1.3, ... up4.0 = bit 15, up4.3 = bit 16); at most 4096 launches
+ * are recorded. timing_read waits for the recorded events and returns, per
+ * conv, the summed milliseconds and the number of launches, then disarms. */
+int exaspim_unet_timing_begin(exaspim_unet* h, uint32_t conv_mask);
+int exaspim_unet_timing_read(exaspim_unet* h, double ms_sum[17], int32_t count[17]);
+
 /* ---- pre-processing: replaces np.minimum + img_util.normalize +
  *      _get_batch_inputs (inference.py:79-80,166-192;
  *      utils/img_util.py:362-379,405-428,504-533) ------------------------- */
