@@ -82,14 +82,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_kernel(
     ConvArgs a, int tiles_z, int tiles_y, int tiles_x) {
     constexpr int G = Tag::kG;            // elements per 16 B
     constexpr int KC = 2 * G;             // channels per chunk
+    constexpr int ES = 16 / G;            // element size in bytes
     constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
-    constexpr int HV = HZ * HY * HX;      // halo voxels
-    constexpr int HVP = (HV + 1) & ~1;    // plane stride (16-byte units)
+    constexpr int HV = HZ * HY * HX;      // halo voxels; LDS image = [2 groups][HV] x 16 B
     constexpr int NTHREADS = WAVES_M * WAVES_N * 64;
     constexpr int TILE_VOX = TZ * TY * TX;
+    constexpr int NITEMS = (2 * HV + NTHREADS - 1) / NTHREADS;  // 16-byte pieces per thread
+    constexpr int PD = 3;                 // weight prefetch distance (taps)
     static_assert(WAVES_M * MT * 32 >= TILE_VOX, "tile not covered by the waves");
 
-    __shared__ uint4 lds[2 * HVP];
+    __shared__ __attribute__((aligned(16))) uint4 lds[2 * HV];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -99,7 +101,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_kernel(
     const int half = lane >> 5;
     const int r = lane & 31;
 
-    int bid = blockIdx.x;
+    // XCD-aware block order: workgroups b, b+8, ... share an XCD (round-robin
+    // dispatch), so give each XCD a contiguous run of tiles -- neighbouring
+    // tiles then find each other's halo voxels in the same 4 MiB L2.
+    int bid;
+    {
+        const int nblk = gridDim.x, q = nblk >> 3, rem = nblk & 7;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
+    }
     const int tx = bid % tiles_x; bid /= tiles_x;
     const int ty = bid % tiles_y; bid /= tiles_y;
     const int tz = bid % tiles_z; bid /= tiles_z;
@@ -115,7 +125,23 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_kernel(
         int m = (wm * MT + mt) * 32 + r;
         m = m < TILE_VOX ? m : TILE_VOX - 1;
         const int z = m / (TY * TX), y = (m / TX) % TY, x = m % TX;
-        base[mt] = (z * HY + y) * HX + x + half * HVP;
+        base[mt] = (z * HY + y) * HX + x + half * HV;
+    }
+
+    // Per-thread staging descriptors: piece i = tid + it * NTHREADS of the LDS
+    // image is channel group (i >= HV) of halo voxel (i mod HV); its source is
+    // voxel vidx[it] of this patch, or nothing (conv zero padding / tile tail).
+    const size_t patch_vox = (size_t)a.d * a.h * a.w;
+    int vidx[NITEMS];
+#pragma unroll
+    for (int it = 0; it < NITEMS; ++it) {
+        const int i = tid + it * NTHREADS;
+        const int hv = i >= HV ? i - HV : i;
+        const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
+        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool ok = i < 2 * HV && (unsigned)gz < (unsigned)a.d &&
+                        (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
+        vidx[it] = ok ? (gz * a.h + gy) * a.w + gx : -1;
     }
 
     f32x16 acc[MT][NT];
@@ -127,7 +153,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_kernel(
             for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
     const int nchunks = (a.ca + a.cb) / KC;
-    const int es = 16 / G;
     for (int c = 0; c < nchunks; ++c) {
         const char* src;
         int cs, ch0;
@@ -136,36 +161,52 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_kernel(
         } else {
             src = static_cast<const char*>(a.src_b); cs = a.cb; ch0 = c * KC - a.ca;
         }
+        const uint4* wp = static_cast<const uint4*>(a.weights) +
+                          ((size_t)c * 27 * ntiles + ntile0) * 64 + lane;
+        // first weight fragments of the chunk: in flight while the halo streams in
+        uint4 wring[PD + 1][NT];
+#pragma unroll
+        for (int t = 0; t < PD; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wring[t][nt] = wp[((size_t)t * ntiles + nt) * 64];
+
         __syncthreads();  // every wave is done reading the previous chunk
-        for (int i = tid; i < 2 * HV; i += NTHREADS) {
-            const int kg = i >= HV ? 1 : 0;
-            const int hv = i - kg * HV;
-            const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
-            const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if ((unsigned)gz < (unsigned)a.d && (unsigned)gy < (unsigned)a.h &&
-                (unsigned)gx < (unsigned)a.w) {
-                const size_t vox = (((size_t)nb * a.d + gz) * a.h + gy) * a.w + gx;
-                v = *reinterpret_cast<const uint4*>(src + (vox * cs + ch0 + kg * G) * es);
+        {
+            // LDS-DMA staging: buffer_load_dwordx4 ... lds writes 16 B per lane at
+            // (wave base + lane * 16) with no register round trip; out-of-range
+            // offsets return zeros = the conv's zero padding.
+            const size_t rec_bytes = patch_vox * cs * ES;
+            __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(src) + (size_t)nb * rec_bytes, 0, (int)rec_bytes, 0x00020000);
+#pragma unroll
+            for (int it = 0; it < NITEMS; ++it) {
+                const int i = tid + it * NTHREADS;
+                if (i < 2 * HV) {
+                    const int kg = i >= HV ? 1 : 0;
+                    const unsigned off = vidx[it] >= 0
+                                             ? (unsigned)((vidx[it] * cs + ch0 + kg * G) * ES)
+                                             : 0x80000000u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        rsrc, (__attribute__((address_space(3))) void*)(lds + i), 16, off, 0, 0, 0);
+                }
             }
-            lds[kg * HVP + hv] = v;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
 
-        const uint4* wp = static_cast<const uint4*>(a.weights) +
-                          ((size_t)c * 27 * ntiles + ntile0) * 64 + lane;
 #pragma unroll
         for (int t = 0; t < 27; ++t) {
-            constexpr int dummy = 0; (void)dummy;
             const int tapoff = ((t / 9) * HY + (t / 3) % 3) * HX + t % 3;
-            uint4 wf[NT];
+            if (t + PD < 27) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wf[nt] = wp[((size_t)t * ntiles + nt) * 64];
+                for (int nt = 0; nt < NT; ++nt)
+                    wring[(t + PD) % (PD + 1)][nt] = wp[((size_t)(t + PD) * ntiles + nt) * 64];
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const uint4 xf = lds[base[mt] + tapoff];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) mma<Tag>(acc[mt][nt], wf[nt], xf);
+                for (int nt = 0; nt < NT; ++nt) mma<Tag>(acc[mt][nt], wring[t % (PD + 1)][nt], xf);
             }
         }
     }
@@ -253,6 +294,11 @@ int launch_conv3x3x3(int dtype, const ConvArgs& a, hipStream_t stream) {
     EXA_CHECK_ARG(a.ca % kc == 0 && a.cb % kc == 0 && a.cout % 32 == 0 && a.ca > 0,
                   "conv: channels (%d,%d)->%d not padded", a.ca, a.cb, a.cout);
     EXA_CHECK_ARG(a.n > 0 && a.d > 0 && a.h > 0 && a.w > 0, "conv: empty input");
+    {   // the LDS-DMA staging addresses one patch of one source with 32-bit offsets
+        const unsigned long long rec = (unsigned long long)a.d * a.h * a.w *
+                                       (a.ca > a.cb ? a.ca : a.cb) * (dtype == EXASPIM_DT_F32 ? 4 : 2);
+        EXA_CHECK_ARG(rec < 0x80000000ULL, "conv: one patch of one source is %llu bytes (>= 2 GiB)", rec);
+    }
     switch (dtype) {
         case EXASPIM_DT_F32: return launch_typed<F32Tag>(a, stream);
         case EXASPIM_DT_BF16: return launch_typed<BF16Tag>(a, stream);

@@ -67,8 +67,9 @@ struct F16T {
 };
 
 // ---- inc.0 ------------------------------------------------------------------
-// One thread = one voxel x 8 output channels; blockIdx.y selects the channel
-// octet, so the 27 x 8 weights are wave-uniform (scalar loads).
+// One thread = one voxel x 32 output channels (blockIdx.y selects the group of
+// 32), so the 27 x 32 weights are wave-uniform scalar loads and every input
+// voxel is read once per tap; loads are clamped + selected instead of branched.
 template <typename T>
 __global__ __launch_bounds__(256) void conv_first_kernel(
     const float* __restrict__ x, const float* __restrict__ w,
@@ -77,46 +78,45 @@ __global__ __launch_bounds__(256) void conv_first_kernel(
     const size_t nvox = (size_t)n * d * h * wd;
     const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nvox) return;
-    const int co0 = blockIdx.y * 8;
+    const int co0 = blockIdx.y * 32;
     const int xx = (int)(v % wd);
     size_t t = v / wd;
     const int yy = (int)(t % h); t /= h;
     const int zz = (int)(t % d);
     const size_t nb = t / d;
-    float acc[8];
+    float acc[32];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = bias[co0 + j];
+    for (int j = 0; j < 32; ++j) acc[j] = bias[co0 + j];
     const float* xp = x + nb * (size_t)d * h * wd;
 #pragma unroll
     for (int kz = 0; kz < 3; ++kz) {
         const int z = zz + kz - 1;
+        const bool zok = (unsigned)z < (unsigned)d;
+        const int zc = min(max(z, 0), d - 1);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int y = yy + ky - 1;
+            const bool yok = zok && (unsigned)y < (unsigned)h;
+            const int yc = min(max(y, 0), h - 1);
+            const float* row = xp + ((size_t)zc * h + yc) * wd;
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int xq = xx + kx - 1;
-                float xv = 0.f;
-                if ((unsigned)z < (unsigned)d && (unsigned)y < (unsigned)h &&
-                    (unsigned)xq < (unsigned)wd)
-                    xv = xp[((size_t)z * h + y) * wd + xq];
+                const bool ok = yok && (unsigned)xq < (unsigned)wd;
+                const float xv = ok ? row[min(max(xq, 0), wd - 1)] : 0.f;
                 const float* wt = w + (size_t)((kz * 3 + ky) * 3 + kx) * c0p + co0;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv, wt[j], acc[j]);
+                for (int j = 0; j < 32; ++j) acc[j] = fmaf(xv, wt[j], acc[j]);
             }
         }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = acc[j] > 0.f ? acc[j] : acc[j] * slope;
+    for (int j = 0; j < 32; ++j) acc[j] = acc[j] > 0.f ? acc[j] : acc[j] * slope;
     constexpr int G = T::kG;
     uint4* out = reinterpret_cast<uint4*>(static_cast<char*>(dst) +
                                           (v * c0p + co0) * (16 / G));
-    if (G == 8) {
-        out[0] = T::pack(acc);
-    } else {
-        out[0] = T::pack(acc);
-        out[1] = T::pack(acc + 4);
-    }
+#pragma unroll
+    for (int g = 0; g < 32 / G; ++g) out[g] = T::pack(acc + g * G);
 }
 
 // ---- max-pool 2x2x2 ----------------------------------------------------------
@@ -259,8 +259,8 @@ int launch_conv_first(int dtype, const float* x, const float* w, const float* bi
                       hipStream_t stream) {
     const size_t nvox = (size_t)n * d * h * wd;
     const size_t blocks = (nvox + 255) / 256;
-    EXA_CHECK_ARG(blocks > 0 && blocks < 0x7fffffffULL && c0p % 8 == 0, "conv_first: bad size");
-    dim3 grid((unsigned)blocks, c0p / 8);
+    EXA_CHECK_ARG(blocks > 0 && blocks < 0x7fffffffULL && c0p % 32 == 0, "conv_first: bad size");
+    dim3 grid((unsigned)blocks, c0p / 32);
     DISPATCH_T(dtype, (conv_first_kernel<T><<<grid, 256, 0, stream>>>(x, w, bias, dst, n, d, h, wd, c0p, slope)));
     EXA_CHECK_HIP(hipGetLastError());
     return EXASPIM_OK;

@@ -136,6 +136,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    with torch.cuda.device(device):
+        model._ensure_engine(device)  # pack + upload weights before anything is timed
     for _ in range(args.warmup):
         out = step()
         del out
