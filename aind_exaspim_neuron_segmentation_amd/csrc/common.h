@@ -88,6 +88,7 @@ struct ConvArgs {
     int cout;            // padded
     int n, d, h, w;      // batch of patches and their spatial size at this level
     float slope;
+    int debug = 0;       // ablation switches (EXASPIM_CONV_DEBUG), 0 in production
 };
 
 int launch_conv3x3x3(int dtype, const ConvArgs& a, hipStream_t stream);

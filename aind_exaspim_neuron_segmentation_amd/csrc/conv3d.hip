@@ -23,6 +23,8 @@
 // f32 uses v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 4 per chunk-tap),
 // bf16/f16 use v_mfma_f32_32x32x16_{bf16,f16} (one per chunk-tap).
 
+#include <cstdlib>
+
 #include "common.h"
 
 namespace exaspim {
@@ -77,7 +79,7 @@ __device__ __forceinline__ void store4<F16Tag>(void* dst, size_t off, float a, f
     *reinterpret_cast<f16x4*>(static_cast<_Float16*>(dst) + off) = v;
 }
 
-template <typename Tag, int TZ, int TY, int TX, int WAVES_M, int WAVES_N, int MT, int NT, int MINW>
+template <typename Tag, int TZ, int TY, int TX, int WAVES_M, int WAVES_N, int MT, int NT, int MINW, int PD = 3>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_kernel(
     ConvArgs a, int tiles_z, int tiles_y, int tiles_x) {
     constexpr int G = Tag::kG;            // elements per 16 B
@@ -88,7 +90,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_kernel(
     constexpr int NTHREADS = WAVES_M * WAVES_N * 64;
     constexpr int TILE_VOX = TZ * TY * TX;
     constexpr int NITEMS = (2 * HV + NTHREADS - 1) / NTHREADS;  // 16-byte pieces per thread
-    constexpr int PD = 3;                 // weight prefetch distance (taps)
     static_assert(WAVES_M * MT * 32 >= TILE_VOX, "tile not covered by the waves");
 
     __shared__ __attribute__((aligned(16))) uint4 lds[2 * HV];
@@ -240,10 +241,218 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_kernel(
     }
 }
 
+// ---- v3: register-staged prefetch (async-STAGE split), deeper operand
+// pipelining and an LDS-transposed epilogue -------------------------------------
+// Same tiling and LDS image as above. Differences:
+//  * the next chunk's halo pieces are loaded global -> VGPR late in the current
+//    chunk's tap loop (after every weight load of the chunk has been issued, so
+//    the in-order vmcnt never makes a weight wait behind the prefetch), and are
+//    written to LDS after the chunk's last MFMA: HBM/L2 latency hides under MFMAs
+//    of the same workgroup instead of relying on a second workgroup;
+//  * x fragments are double-buffered per tap (all MT reads of tap t+1 in flight
+//    under the MFMAs of tap t);
+//  * outputs go through LDS so every store instruction writes whole 16-byte
+//    pieces of consecutive voxel records (1 KiB contiguous per instruction when
+//    the tile row is 16 voxels of 32 channels).
+template <typename Tag, int TZ, int TY, int TX, int WAVES_M, int WAVES_N, int MT, int NT, int MINW, int PD>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
+    ConvArgs a, int tiles_z, int tiles_y, int tiles_x) {
+    constexpr int G = Tag::kG;
+    constexpr int KC = 2 * G;
+    constexpr int ES = 16 / G;
+    constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+    constexpr int HV = HZ * HY * HX;
+    constexpr int NWAVES = WAVES_M * WAVES_N;
+    constexpr int NTHREADS = NWAVES * 64;
+    constexpr int TILE_VOX = TZ * TY * TX;
+    constexpr int NITEMS = (2 * HV + NTHREADS - 1) / NTHREADS;
+    constexpr int RECB = NT * 32 * ES;              // bytes of one voxel's output slice
+    constexpr int EPI_UNITS = NWAVES * 32 * RECB / 16;
+    constexpr int LDS_UNITS = 2 * HV > EPI_UNITS ? 2 * HV : EPI_UNITS;
+    constexpr int ISSUE_T = 26 - PD > 0 ? 26 - PD : 0;  // tap at which the prefetch is issued
+    static_assert(WAVES_M * MT * 32 >= TILE_VOX, "tile not covered by the waves");
+
+    __shared__ __attribute__((aligned(16))) uint4 lds[LDS_UNITS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N;
+    const int wn = wave % WAVES_N;
+    const int half = lane >> 5;
+    const int r = lane & 31;
+
+    int bid;
+    {
+        const int nblk = gridDim.x, q = nblk >> 3, rem = nblk & 7;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
+    }
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y; bid /= tiles_y;
+    const int tz = bid % tiles_z; bid /= tiles_z;
+    const int nb = bid;
+    const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
+
+    const int ntiles = a.cout >> 5;
+    const int ntile0 = (blockIdx.y * WAVES_N + wn) * NT;
+
+    int base[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int m = (wm * MT + mt) * 32 + r;
+        m = m < TILE_VOX ? m : TILE_VOX - 1;
+        const int z = m / (TY * TX), y = (m / TX) % TY, x = m % TX;
+        base[mt] = (z * HY + y) * HX + x + half * HV;
+    }
+
+    const size_t patch_vox = (size_t)a.d * a.h * a.w;
+    int vidx[NITEMS];
+#pragma unroll
+    for (int it = 0; it < NITEMS; ++it) {
+        const int i = tid + it * NTHREADS;
+        const int hv = i >= HV ? i - HV : i;
+        const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
+        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool ok = i < 2 * HV && (unsigned)gz < (unsigned)a.d &&
+                        (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
+        vidx[it] = ok ? (gz * a.h + gy) * a.w + gx : -1;
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+
+    const int nchunks = (a.ca + a.cb) / KC;
+    uint4 stg[NITEMS];
+
+    auto stage_load = [&](int c) {
+        const char* src;
+        int cs, ch0;
+        if (c * KC < a.ca) {
+            src = static_cast<const char*>(a.src_a); cs = a.ca; ch0 = c * KC;
+        } else {
+            src = static_cast<const char*>(a.src_b); cs = a.cb; ch0 = c * KC - a.ca;
+        }
+        const char* pbase = src + (size_t)nb * patch_vox * cs * ES;
+#pragma unroll
+        for (int it = 0; it < NITEMS; ++it) {
+            const int i = tid + it * NTHREADS;
+            const int kg = i >= HV ? 1 : 0;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (vidx[it] >= 0)
+                v = *reinterpret_cast<const uint4*>(
+                    pbase + ((size_t)(unsigned)vidx[it] * cs + ch0 + kg * G) * ES);
+            stg[it] = v;
+        }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int it = 0; it < NITEMS; ++it) {
+            const int i = tid + it * NTHREADS;
+            if (i < 2 * HV) lds[i] = stg[it];
+        }
+    };
+
+    stage_load(0);
+    stage_store();
+    __syncthreads();
+
+    for (int c = 0; c < nchunks; ++c) {
+        const uint4* wp = static_cast<const uint4*>(a.weights) +
+                          ((size_t)c * 27 * ntiles + ntile0) * 64 + lane;
+        uint4 wring[PD + 1][NT];
+#pragma unroll
+        for (int t = 0; t < PD; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wring[t][nt] = wp[((size_t)t * ntiles + nt) * 64];
+
+        uint4 xf[2][MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xf[0][mt] = lds[base[mt]];
+
+        const bool more = c + 1 < nchunks;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            if (t + PD < 27) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    wring[(t + PD) % (PD + 1)][nt] = wp[((size_t)(t + PD) * ntiles + nt) * 64];
+            }
+            if (t == ISSUE_T && more) stage_load(c + 1);
+            if (t + 1 < 27) {
+                const int tapoff = (((t + 1) / 9) * HY + ((t + 1) / 3) % 3) * HX + (t + 1) % 3;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) xf[(t + 1) & 1][mt] = lds[base[mt] + tapoff];
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    mma<Tag>(acc[mt][nt], wring[t % (PD + 1)][nt], xf[t & 1][mt]);
+            // keep each tap's {prefetch issue, fragment reads, MFMAs} together: without
+            // this fence hipcc hoists and sinks them across taps and the loop runs ~20 % slower
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();  // every wave is done reading this chunk's image
+        if (more) {
+            stage_store();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: bias + LeakyReLU, transposed through LDS ------------------
+    char* wl = reinterpret_cast<char*>(lds) + wave * (32 * RECB);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cl = nt * 32 + 8 * q + 4 * half;  // channel inside the slice
+                const float4 b = *reinterpret_cast<const float4*>(a.bias + ntile0 * 32 + cl);
+                float v0 = acc[mt][nt][4 * q + 0] + b.x;
+                float v1 = acc[mt][nt][4 * q + 1] + b.y;
+                float v2 = acc[mt][nt][4 * q + 2] + b.z;
+                float v3 = acc[mt][nt][4 * q + 3] + b.w;
+                v0 = v0 > 0.f ? v0 : v0 * a.slope;
+                v1 = v1 > 0.f ? v1 : v1 * a.slope;
+                v2 = v2 > 0.f ? v2 : v2 * a.slope;
+                v3 = v3 > 0.f ? v3 : v3 * a.slope;
+                store4<Tag>(wl, (size_t)(r * RECB) / ES + cl, v0, v1, v2, v3);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        constexpr int PPV = RECB / 16;           // 16-byte pieces per voxel slice
+        constexpr int ROUNDS = 32 * PPV / 64;
+#pragma unroll
+        for (int k = 0; k < ROUNDS; ++k) {
+            const int p = k * 64 + lane;
+            const int vv = p / PPV, part = p % PPV;
+            const int m = (wm * MT + mt) * 32 + vv;
+            const int z = m / (TY * TX), y = (m / TX) % TY, x = m % TX;
+            const int gz = z0 + z, gy = y0 + y, gx = x0 + x;
+            const uint4 val = *reinterpret_cast<const uint4*>(wl + p * 16);
+            if (m < TILE_VOX && gz < a.d && gy < a.h && gx < a.w) {
+                const size_t vox = (((size_t)nb * a.d + gz) * a.h + gy) * a.w + gx;
+                *reinterpret_cast<uint4*>(static_cast<char*>(a.dst) +
+                                          (vox * a.cout + ntile0 * 32) * ES + part * 16) = val;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---- host side: pick a tile configuration per layer -----------------------
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-template <typename Tag, int TZ, int TY, int TX, int WAVES_M, int WAVES_N, int MT, int NT, int MINW>
+template <typename Tag, int TZ, int TY, int TX, int WAVES_M, int WAVES_N, int MT, int NT, int MINW, int PD = 3>
 static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
     constexpr int NWG = WAVES_N * NT * 32;
     if (a.cout % NWG != 0) {
@@ -257,8 +466,13 @@ static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
         return EXASPIM_E_INVALID;
     }
     dim3 grid((unsigned)blocks, a.cout / NWG);
-    conv3x3x3_kernel<Tag, TZ, TY, TX, WAVES_M, WAVES_N, MT, NT, MINW>
-        <<<grid, WAVES_M * WAVES_N * 64, 0, stream>>>(a, tz, ty, tx);
+    static const int impl = getenv("EXASPIM_CONV_IMPL") ? atoi(getenv("EXASPIM_CONV_IMPL")) : 1;
+    if (impl == 0)
+        conv3x3x3_kernel<Tag, TZ, TY, TX, WAVES_M, WAVES_N, MT, NT, MINW, (PD > 3 ? 3 : PD)>
+            <<<grid, WAVES_M * WAVES_N * 64, 0, stream>>>(a, tz, ty, tx);
+    else
+        conv3x3x3_t14<Tag, TZ, TY, TX, WAVES_M, WAVES_N, MT, NT, MINW, PD>
+            <<<grid, WAVES_M * WAVES_N * 64, 0, stream>>>(a, tz, ty, tx);
     EXA_CHECK_HIP(hipGetLastError());
     return EXASPIM_OK;
 }
@@ -267,10 +481,15 @@ template <typename Tag>
 static int launch_typed(const ConvArgs& a, hipStream_t stream) {
     // Widest x extent first: the tile shapes follow the 96/48/24/12/6 pyramid of
     // a 96^3 patch; any other size runs on the closest shape with masking.
+    static const int l0_variant = getenv("EXASPIM_L0_VARIANT") ? atoi(getenv("EXASPIM_L0_VARIANT")) : 0;
     if (a.w >= 32 && a.w % 32 == 0) {
-        if (a.cout % 64 == 0)
-            return launch_cfg<Tag, 4, 8, 32, 4, 1, 8, 1, 2>(a, stream);  // grid.y = cout/32
-        return launch_cfg<Tag, 4, 8, 32, 4, 1, 8, 1, 2>(a, stream);
+        if (l0_variant == 1) return launch_cfg<Tag, 4, 8, 16, 4, 1, 4, 1, 2, 8>(a, stream);
+        if (l0_variant == 2) return launch_cfg<Tag, 4, 8, 16, 4, 1, 4, 1, 2, 4>(a, stream);
+        if (l0_variant == 3) return launch_cfg<Tag, 4, 8, 32, 4, 1, 8, 1, 2, 4>(a, stream);
+        if (l0_variant == 4) return launch_cfg<Tag, 4, 8, 16, 4, 1, 4, 1, 3, 6>(a, stream);
+        if (l0_variant == 5) return launch_cfg<Tag, 4, 8, 32, 4, 1, 8, 1, 2>(a, stream);
+        if (a.cout % 64 == 0) return launch_cfg<Tag, 4, 8, 16, 4, 1, 4, 2, 2>(a, stream);
+        return launch_cfg<Tag, 4, 8, 16, 4, 1, 4, 1, 2, 8>(a, stream);
     }
     if (a.w >= 16 && a.w % 16 == 0) {
         if (a.cout % 64 == 0) return launch_cfg<Tag, 4, 8, 16, 4, 1, 4, 2, 2>(a, stream);
@@ -299,10 +518,13 @@ int launch_conv3x3x3(int dtype, const ConvArgs& a, hipStream_t stream) {
                                        (a.ca > a.cb ? a.ca : a.cb) * (dtype == EXASPIM_DT_F32 ? 4 : 2);
         EXA_CHECK_ARG(rec < 0x80000000ULL, "conv: one patch of one source is %llu bytes (>= 2 GiB)", rec);
     }
+    static const int debug = getenv("EXASPIM_CONV_DEBUG") ? atoi(getenv("EXASPIM_CONV_DEBUG")) : 0;
+    ConvArgs b = a;
+    b.debug = debug;
     switch (dtype) {
-        case EXASPIM_DT_F32: return launch_typed<F32Tag>(a, stream);
-        case EXASPIM_DT_BF16: return launch_typed<BF16Tag>(a, stream);
-        case EXASPIM_DT_F16: return launch_typed<F16Tag>(a, stream);
+        case EXASPIM_DT_F32: return launch_typed<F32Tag>(b, stream);
+        case EXASPIM_DT_BF16: return launch_typed<BF16Tag>(b, stream);
+        case EXASPIM_DT_F16: return launch_typed<F16Tag>(b, stream);
     }
     set_error("conv: unknown dtype %d", dtype);
     return EXASPIM_E_INVALID;

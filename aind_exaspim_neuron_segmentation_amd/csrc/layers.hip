@@ -67,56 +67,88 @@ struct F16T {
 };
 
 // ---- inc.0 ------------------------------------------------------------------
-// One thread = one voxel x 32 output channels (blockIdx.y selects the group of
-// 32), so the 27 x 32 weights are wave-uniform scalar loads and every input
-// voxel is read once per tap; loads are clamped + selected instead of branched.
-template <typename T>
+// Cin = 1, so the contraction is only over the 27 taps: per 32 voxels x 32
+// output channels it is a 32 x 28 x 32 GEMM (27 taps + one zero column), run as
+// 14 exact-fp32 v_mfma_f32_32x32x2_f32. A = weights W[cout][tap] (14 floats per
+// lane, loaded once per wave), B = X[tap][voxel] gathered straight from the
+// float32 patch (zero outside the patch = the conv padding). The patch is read
+// in fp32 whatever the network's storage type, so inc.0 adds no input rounding.
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+template <typename T, int MT>
 __global__ __launch_bounds__(256) void conv_first_kernel(
     const float* __restrict__ x, const float* __restrict__ w,
-    const float* __restrict__ bias, void* __restrict__ dst, int n, int d, int h, int wd,
+    const float* __restrict__ bias, void* __restrict__ dst, int nvox, int d, int h, int wd,
     int c0p, float slope) {
-    const size_t nvox = (size_t)n * d * h * wd;
-    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= nvox) return;
-    const int co0 = blockIdx.y * 32;
-    const int xx = (int)(v % wd);
-    size_t t = v / wd;
-    const int yy = (int)(t % h); t /= h;
-    const int zz = (int)(t % d);
-    const size_t nb = t / d;
-    float acc[32];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int half = lane >> 5, r = lane & 31;
+    const int co_tile = blockIdx.y * 32;
+    const int hw = h * wd, dhw = d * hw;
+
+    // this lane's 14 taps (k = 2 * ks + half): weight and relative input offset
+    float wk[14];
+    int rel[14], dzyx[14];
 #pragma unroll
-    for (int j = 0; j < 32; ++j) acc[j] = bias[co0 + j];
-    const float* xp = x + nb * (size_t)d * h * wd;
+    for (int ks = 0; ks < 14; ++ks) {
+        const int t = 2 * ks + half;
+        const bool real = t < 27;
+        const int tt = real ? t : 0;
+        const int dz = tt / 9 - 1, dy = (tt / 3) % 3 - 1, dx = tt % 3 - 1;
+        wk[ks] = real ? w[tt * c0p + co_tile + r] : 0.f;
+        rel[ks] = dz * hw + dy * wd + dx;
+        dzyx[ks] = real ? ((dz + 1) | ((dy + 1) << 2) | ((dx + 1) << 4)) : 0x40;
+    }
+
+    const int v0 = (blockIdx.x * 4 + wave) * (MT * 32);
+    f32x16_t acc[MT];
+    float xv[MT][14];
 #pragma unroll
-    for (int kz = 0; kz < 3; ++kz) {
-        const int z = zz + kz - 1;
-        const bool zok = (unsigned)z < (unsigned)d;
-        const int zc = min(max(z, 0), d - 1);
+    for (int mt = 0; mt < MT; ++mt) {
+        const int v = v0 + mt * 32 + r;
+        const int vc = v < nvox ? v : nvox - 1;
+        const int sp = vc % dhw;
+        const int zz = sp / hw, yy = (sp / wd) % h, xx = sp % wd;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int y = yy + ky - 1;
-            const bool yok = zok && (unsigned)y < (unsigned)h;
-            const int yc = min(max(y, 0), h - 1);
-            const float* row = xp + ((size_t)zc * h + yc) * wd;
+        for (int ks = 0; ks < 14; ++ks) {
+            const int c = dzyx[ks];
+            const int z = zz + (c & 3) - 1, y = yy + ((c >> 2) & 3) - 1, xq = xx + ((c >> 4) & 3) - 1;
+            const bool ok = c < 0x40 && (unsigned)z < (unsigned)d && (unsigned)y < (unsigned)h &&
+                            (unsigned)xq < (unsigned)wd;
+            xv[mt][ks] = ok ? x[vc + rel[ks]] : 0.f;
+        }
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int xq = xx + kx - 1;
-                const bool ok = yok && (unsigned)xq < (unsigned)wd;
-                const float xv = ok ? row[min(max(xq, 0), wd - 1)] : 0.f;
-                const float* wt = w + (size_t)((kz * 3 + ky) * 3 + kx) * c0p + co0;
+        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+    }
 #pragma unroll
-                for (int j = 0; j < 32; ++j) acc[j] = fmaf(xv, wt[j], acc[j]);
+    for (int ks = 0; ks < 14; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[ks], xv[mt][ks], acc[mt], 0, 0, 0);
+
+    constexpr int G = T::kG;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int v = v0 + mt * 32 + r;
+        if (v >= nvox) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int co = co_tile + 8 * q + 4 * half;
+            const float4 b = *reinterpret_cast<const float4*>(bias + co);
+            float o[4] = {acc[mt][4 * q] + b.x, acc[mt][4 * q + 1] + b.y,
+                          acc[mt][4 * q + 2] + b.z, acc[mt][4 * q + 3] + b.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = o[j] > 0.f ? o[j] : o[j] * slope;
+            char* out = static_cast<char*>(dst) + ((size_t)v * c0p + co) * (16 / G);
+            if (G == 4) {
+                *reinterpret_cast<float4*>(out) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+                float o8[8] = {o[0], o[1], o[2], o[3], 0.f, 0.f, 0.f, 0.f};
+                const uint4 pk = T::pack(o8);
+                *reinterpret_cast<uint2*>(out) = make_uint2(pk.x, pk.y);
             }
         }
     }
-#pragma unroll
-    for (int j = 0; j < 32; ++j) acc[j] = acc[j] > 0.f ? acc[j] : acc[j] * slope;
-    constexpr int G = T::kG;
-    uint4* out = reinterpret_cast<uint4*>(static_cast<char*>(dst) +
-                                          (v * c0p + co0) * (16 / G));
-#pragma unroll
-    for (int g = 0; g < 32 / G; ++g) out[g] = T::pack(acc + g * G);
 }
 
 // ---- max-pool 2x2x2 ----------------------------------------------------------
@@ -258,10 +290,11 @@ int launch_conv_first(int dtype, const float* x, const float* w, const float* bi
                       void* dst, int n, int d, int h, int wd, int c0p, float slope,
                       hipStream_t stream) {
     const size_t nvox = (size_t)n * d * h * wd;
-    const size_t blocks = (nvox + 255) / 256;
-    EXA_CHECK_ARG(blocks > 0 && blocks < 0x7fffffffULL && c0p % 32 == 0, "conv_first: bad size");
+    constexpr int MT = 4;
+    const size_t blocks = (nvox + 4 * MT * 32 - 1) / (4 * MT * 32);
+    EXA_CHECK_ARG(nvox > 0 && nvox < 0x7fffffffULL && c0p % 32 == 0, "conv_first: bad size");
     dim3 grid((unsigned)blocks, c0p / 32);
-    DISPATCH_T(dtype, (conv_first_kernel<T><<<grid, 256, 0, stream>>>(x, w, bias, dst, n, d, h, wd, c0p, slope)));
+    DISPATCH_T(dtype, (conv_first_kernel<T, MT><<<grid, 256, 0, stream>>>(x, w, bias, dst, (int)nvox, d, h, wd, c0p, slope)));
     EXA_CHECK_HIP(hipGetLastError());
     return EXASPIM_OK;
 }
