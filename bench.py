@@ -182,11 +182,18 @@ def main():
         flops *= patches_per_step / float(full_batches * args.batch)
         achieved = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.dtype]
+        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC
+        # passes (FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md says;
+        # profiles/summarize.py); null when no pass exists for this dtype.
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_conv_level0.json")
+        tpath = os.path.join(ROOT, "profiles", f"r01_pmc_hbm_{args.dtype}.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get(args.dtype)
+                kernels = json.load(f).get("kernels", {})
+            tag = {"bf16": "BF16Tag", "fp16": "F16Tag", "fp32": "F32Tag"}[args.dtype]
+            entry = kernels.get(f"conv3x3x3_t14<{tag}, 4, 8, 16, 4, 1, 4, 1, 2, 8>")
+            if entry:
+                traffic = entry["hbm_bytes_per_launch"]
         result = {
             "metric": "affinity voxels/sec on 96^3 patches over a 1024^3 volume",
             "value": value,
@@ -213,7 +220,8 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "conv3x3x3_kernel<tile 4x8x32> (96^3-level convs inc.3, up4.0, up4.3)",
+                "kernel": "conv3x3x3_t14<4x8x16 tile, 32 couts> (the 96^3-level convs inc.3, up4.0, up4.3)",
+                "algorithmic_flop_per_launch": flops / launches if launches else None,
                 "achieved": achieved,
                 "peak": peak,
                 "unit": "TFLOP/s",
