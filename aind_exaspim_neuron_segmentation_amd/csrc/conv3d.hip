@@ -449,6 +449,274 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
     }
 }
 
+// ---- v4: z-column tiles ---------------------------------------------------
+// As v3, but a wave owns COLUMNS of the tile: YXW groups of 32 (y, x) positions
+// times all TZ planes (MT = TZ * YXW accumulators). For a fixed in-plane tap
+// (dy, dx) the operand fragment of input plane zin is the B operand of up to
+// three MFMAs (dz = 0, 1, 2 -> output planes zin, zin-1, zin-2), so the N = 32
+// GEMM needs (TZ + 2) LDS reads per 3 * TZ MFMAs instead of one read per MFMA.
+// Halo rows are padded to HXP = TX (mod 16) 16-byte slots so that the two
+// half-rows of a 32-voxel group never share a bank (no LDS conflicts for 16-
+// wide rows); padding slots are never written or read.
+// With WLDS the chunk's 27 weight fragments are staged in LDS as well (prefetched
+// global -> VGPR with the halo, one copy per workgroup instead of one L2 read per
+// wave): with 4 x 32-voxel tiles per wave the per-wave weight stream would
+// otherwise be 3x the activation traffic.
+template <typename Tag, int TZ, int TY, int TX, int WAVES_M, int WAVES_N, int YXW, int NT, int MINW, int PDG, bool WLDS, bool PADX = true>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_zcol(
+    ConvArgs a, int tiles_z, int tiles_y, int tiles_x) {
+    constexpr int G = Tag::kG;
+    constexpr int KC = 2 * G;
+    constexpr int ES = 16 / G;
+    constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+    constexpr int HXP = (TX == 32 || !PADX) ? HX : (HX + 15) / 16 * 16 + (TX % 16);  // row stride (slots)
+    constexpr int HV = HZ * HY * HX;       // real halo voxels (staging items per group)
+    constexpr int HVP = HZ * HY * HXP;     // slots per channel group
+    constexpr int NWAVES = WAVES_M * WAVES_N;
+    constexpr int NTHREADS = NWAVES * 64;
+    constexpr int YXT = TY * TX / 32;      // 32-voxel (y, x) groups per plane
+    constexpr int MT = TZ * YXW;
+    constexpr int NITEMS = (2 * HV + NTHREADS - 1) / NTHREADS;
+    constexpr int RECB = NT * 32 * ES;
+    constexpr int EPI_UNITS = NWAVES * 32 * RECB / 16;
+    constexpr int WUNITS = WLDS ? 27 * NT * 64 : 0;           // weight fragments in LDS
+    constexpr int WITEMS = (WUNITS + NTHREADS - 1) / NTHREADS;
+    constexpr int XUNITS = 2 * HVP > EPI_UNITS ? 2 * HVP : EPI_UNITS;
+    constexpr int LDS_UNITS = XUNITS + WUNITS;
+    static_assert(TY * TX % 32 == 0 && YXT == WAVES_M * YXW, "plane not covered by the waves");
+    static_assert(!WLDS || WAVES_N == 1, "LDS weights assume one cout slice per workgroup");
+
+    __shared__ __attribute__((aligned(16))) uint4 lds[LDS_UNITS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N;
+    const int wn = wave % WAVES_N;
+    const int half = lane >> 5;
+    const int r = lane & 31;
+
+    int bid;
+    {
+        const int nblk = gridDim.x, q = nblk >> 3, rem = nblk & 7;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
+    }
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y; bid /= tiles_y;
+    const int tz = bid % tiles_z; bid /= tiles_z;
+    const int nb = bid;
+    const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
+
+    const int ntiles = a.cout >> 5;
+    const int ntile0 = (blockIdx.y * WAVES_N + wn) * NT;
+
+    // slot of this lane's voxel in plane 0 for each of the wave's (y, x) groups
+    int col[YXW];
+#pragma unroll
+    for (int j = 0; j < YXW; ++j) {
+        const int p = (wm * YXW + j) * 32 + r;  // position inside the plane
+        col[j] = (p / TX) * HXP + (p % TX) + half * HVP;
+    }
+
+    const size_t patch_vox = (size_t)a.d * a.h * a.w;
+    int vidx[NITEMS];   // source voxel of staging item, or -1
+    int slot[NITEMS];   // its LDS slot
+#pragma unroll
+    for (int it = 0; it < NITEMS; ++it) {
+        const int i = tid + it * NTHREADS;
+        const int kg = i >= HV ? 1 : 0;
+        const int hv = i - kg * HV;
+        const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
+        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool inr = i < 2 * HV;
+        const bool ok = inr && (unsigned)gz < (unsigned)a.d && (unsigned)gy < (unsigned)a.h &&
+                        (unsigned)gx < (unsigned)a.w;
+        vidx[it] = ok ? (gz * a.h + gy) * a.w + gx : -1;
+        slot[it] = inr ? kg * HVP + (hz * HY + hy) * HXP + hx : -1;
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+
+    const int nchunks = (a.ca + a.cb) / KC;
+    uint4 stg[NITEMS + WITEMS];  // halo pieces, then weight fragments
+    uint4* const wlds = lds + XUNITS;
+
+    auto stage_load = [&](int c) {
+        const char* src;
+        int cs, ch0;
+        if (c * KC < a.ca) {
+            src = static_cast<const char*>(a.src_a); cs = a.ca; ch0 = c * KC;
+        } else {
+            src = static_cast<const char*>(a.src_b); cs = a.cb; ch0 = c * KC - a.ca;
+        }
+        const char* pbase = src + (size_t)nb * patch_vox * cs * ES;
+#pragma unroll
+        for (int it = 0; it < NITEMS; ++it) {
+            const int i = tid + it * NTHREADS;
+            const int kg = i >= HV ? 1 : 0;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (vidx[it] >= 0)
+                v = *reinterpret_cast<const uint4*>(
+                    pbase + ((size_t)(unsigned)vidx[it] * cs + ch0 + kg * G) * ES);
+            stg[it] = v;
+        }
+        if (WLDS) {
+            const uint4* wsrc = static_cast<const uint4*>(a.weights) + (size_t)c * 27 * ntiles * 64;
+#pragma unroll
+            for (int it = 0; it < WITEMS; ++it) {
+                const int i = tid + it * NTHREADS;
+                const int tap = i / (NT * 64), rest = i % (NT * 64);
+                if (i < WUNITS) stg[NITEMS + it] = wsrc[((size_t)tap * ntiles + ntile0) * 64 + rest];
+            }
+        }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int it = 0; it < NITEMS; ++it)
+            if (slot[it] >= 0) lds[slot[it]] = stg[it];
+        if (WLDS) {
+#pragma unroll
+            for (int it = 0; it < WITEMS; ++it) {
+                const int i = tid + it * NTHREADS;
+                if (i < WUNITS) wlds[i] = stg[NITEMS + it];
+            }
+        }
+    };
+
+    stage_load(0);
+    stage_store();
+    __syncthreads();
+
+    for (int c = 0; c < nchunks; ++c) {
+        const uint4* wp = static_cast<const uint4*>(a.weights) +
+                          ((size_t)c * 27 * ntiles + ntile0) * 64 + lane;
+        // weight ring over in-plane taps g = dy * 3 + dx: three fragments (dz) each
+        uint4 wring[PDG + 1][3][NT];
+        if (!WLDS)
+#pragma unroll
+        for (int g = 0; g < PDG; ++g)
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    wring[g][dz][nt] = wp[((size_t)(dz * 9 + g) * ntiles + nt) * 64];
+
+        const bool more = c + 1 < nchunks;
+#pragma unroll
+        for (int g = 0; g < 9; ++g) {
+            if (WLDS) {
+#pragma unroll
+                for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        wring[g % (PDG + 1)][dz][nt] = wlds[((dz * 9 + g) * NT + nt) * 64 + lane];
+            } else if (g + PDG < 9) {
+#pragma unroll
+                for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        wring[(g + PDG) % (PDG + 1)][dz][nt] =
+                            wp[((size_t)(dz * 9 + g + PDG) * ntiles + nt) * 64];
+            }
+            if (g == (WLDS ? 0 : 9 - PDG - 1) && more) stage_load(c + 1);
+            const int goff = (g / 3) * HXP + g % 3;
+#pragma unroll
+            for (int j = 0; j < YXW; ++j) {
+                uint4 xf[HZ];
+#pragma unroll
+                for (int zin = 0; zin < HZ; ++zin) xf[zin] = lds[col[j] + zin * HY * HXP + goff];
+#pragma unroll
+                for (int zin = 0; zin < HZ; ++zin)
+#pragma unroll
+                    for (int dz = 0; dz < 3; ++dz) {
+                        const int z = zin - dz;
+                        if (z >= 0 && z < TZ) {
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                mma<Tag>(acc[j * TZ + z][nt], wring[g % (PDG + 1)][dz][nt], xf[zin]);
+                        }
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        if (more) {
+            stage_store();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: bias + LeakyReLU, transposed through LDS ------------------
+    char* wl = reinterpret_cast<char*>(lds) + wave * (32 * RECB);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int j = mt / TZ, z = mt % TZ;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cl = nt * 32 + 8 * q + 4 * half;
+                const float4 b = *reinterpret_cast<const float4*>(a.bias + ntile0 * 32 + cl);
+                float v0 = acc[mt][nt][4 * q + 0] + b.x;
+                float v1 = acc[mt][nt][4 * q + 1] + b.y;
+                float v2 = acc[mt][nt][4 * q + 2] + b.z;
+                float v3 = acc[mt][nt][4 * q + 3] + b.w;
+                v0 = v0 > 0.f ? v0 : v0 * a.slope;
+                v1 = v1 > 0.f ? v1 : v1 * a.slope;
+                v2 = v2 > 0.f ? v2 : v2 * a.slope;
+                v3 = v3 > 0.f ? v3 : v3 * a.slope;
+                store4<Tag>(wl, (size_t)(r * RECB) / ES + cl, v0, v1, v2, v3);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        constexpr int PPV = RECB / 16;
+        constexpr int ROUNDS = 32 * PPV / 64;
+#pragma unroll
+        for (int k = 0; k < ROUNDS; ++k) {
+            const int p = k * 64 + lane;
+            const int vv = p / PPV, part = p % PPV;
+            const int pos = (wm * YXW + j) * 32 + vv;
+            const int gz = z0 + z, gy = y0 + pos / TX, gx = x0 + pos % TX;
+            const uint4 val = *reinterpret_cast<const uint4*>(wl + p * 16);
+            if (gz < a.d && gy < a.h && gx < a.w) {
+                const size_t vox = (((size_t)nb * a.d + gz) * a.h + gy) * a.w + gx;
+                *reinterpret_cast<uint4*>(static_cast<char*>(a.dst) +
+                                          (vox * a.cout + ntile0 * 32) * ES + part * 16) = val;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <typename Tag, int TZ, int TY, int TX, int WAVES_M, int WAVES_N, int YXW, int NT, int MINW, int PDG, bool WLDS = false, bool PADX = true>
+static int launch_zcol(const ConvArgs& a, hipStream_t stream) {
+    constexpr int NWG = WAVES_N * NT * 32;
+    if (a.cout % NWG != 0) {
+        set_error("conv: cout %d not a multiple of the %d-channel tile", a.cout, NWG);
+        return EXASPIM_E_INVALID;
+    }
+    const int tz = (a.d + TZ - 1) / TZ, ty = (a.h + TY - 1) / TY, tx = (a.w + TX - 1) / TX;
+    const long long blocks = (long long)tz * ty * tx * a.n;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) {
+        set_error("conv: grid of %lld blocks out of range", blocks);
+        return EXASPIM_E_INVALID;
+    }
+    dim3 grid((unsigned)blocks, a.cout / NWG);
+    conv3x3x3_zcol<Tag, TZ, TY, TX, WAVES_M, WAVES_N, YXW, NT, MINW, PDG, WLDS, PADX>
+        <<<grid, WAVES_M * WAVES_N * 64, 0, stream>>>(a, tz, ty, tx);
+    EXA_CHECK_HIP(hipGetLastError());
+    return EXASPIM_OK;
+}
+
 // ---- host side: pick a tile configuration per layer -----------------------
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -482,18 +750,15 @@ static int launch_typed(const ConvArgs& a, hipStream_t stream) {
     // Widest x extent first: the tile shapes follow the 96/48/24/12/6 pyramid of
     // a 96^3 patch; any other size runs on the closest shape with masking.
     static const int l0_variant = getenv("EXASPIM_L0_VARIANT") ? atoi(getenv("EXASPIM_L0_VARIANT")) : 0;
-    if (a.w >= 32 && a.w % 32 == 0) {
-        if (l0_variant == 1) return launch_cfg<Tag, 4, 8, 16, 4, 1, 4, 1, 2, 8>(a, stream);
-        if (l0_variant == 2) return launch_cfg<Tag, 4, 8, 16, 4, 1, 4, 1, 2, 4>(a, stream);
-        if (l0_variant == 3) return launch_cfg<Tag, 4, 8, 32, 4, 1, 8, 1, 2, 4>(a, stream);
-        if (l0_variant == 4) return launch_cfg<Tag, 4, 8, 16, 4, 1, 4, 1, 3, 6>(a, stream);
-        if (l0_variant == 5) return launch_cfg<Tag, 4, 8, 32, 4, 1, 8, 1, 2>(a, stream);
-        if (a.cout % 64 == 0) return launch_cfg<Tag, 4, 8, 16, 4, 1, 4, 2, 2>(a, stream);
-        return launch_cfg<Tag, 4, 8, 16, 4, 1, 4, 1, 2, 8>(a, stream);
-    }
+    static const int l1_variant = getenv("EXASPIM_L1_VARIANT") ? atoi(getenv("EXASPIM_L1_VARIANT")) : 0;
     if (a.w >= 16 && a.w % 16 == 0) {
-        if (a.cout % 64 == 0) return launch_cfg<Tag, 4, 8, 16, 4, 1, 4, 2, 2>(a, stream);
-        return launch_cfg<Tag, 4, 8, 16, 4, 1, 4, 1, 2>(a, stream);
+        // z-column tiles, weights shared through LDS, one 32-cout slice per workgroup
+        if (a.cout % 64 != 0) {
+            if (l0_variant == 1) return launch_cfg<Tag, 4, 8, 16, 4, 1, 4, 1, 2, 8>(a, stream);
+            return launch_zcol<Tag, 4, 8, 16, 4, 1, 1, 1, 2, 1, true, false>(a, stream);
+        }
+        if (l1_variant == 1) return launch_zcol<Tag, 4, 8, 16, 4, 1, 1, 1, 2, 1, true, false>(a, stream);
+        return launch_cfg<Tag, 4, 8, 16, 4, 1, 4, 2, 2>(a, stream);
     }
     if (a.w > 12) {
         if (a.cout % 64 == 0) return launch_cfg<Tag, 4, 4, 24, 4, 1, 3, 2, 2>(a, stream);
