@@ -149,13 +149,46 @@ class Shard:
         return tuple(lo), tuple(hi)
 
 
+def _needs_host_staging(tensor, group):
+    """gloo moves CPU tensors only: device tensors are staged through the host
+    (CPU tests, and 2-rank rehearsals on a single GPU); nccl/RCCL moves them
+    directly over xGMI."""
+    import torch.distributed as dist
+
+    return tensor.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def _p2p(ops, group):
+    """Runs a batch of (kind, tensor, peer) point-to-point transfers."""
     import torch.distributed as dist
 
     if not ops:
         return
-    for req in dist.batch_isend_irecv(ops):
+    staged, reqs = [], []
+    for kind, tensor, peer in ops:
+        buf = tensor
+        if _needs_host_staging(tensor, group):
+            buf = tensor.cpu() if kind == "send" else torch.empty(
+                tensor.shape, dtype=tensor.dtype, device="cpu")
+            if kind == "recv":
+                staged.append((tensor, buf))
+        reqs.append(dist.P2POp(dist.isend if kind == "send" else dist.irecv, buf, peer, group))
+    for req in dist.batch_isend_irecv(reqs):
         req.wait()
+    for dst, buf in staged:
+        dst.copy_(buf)
+
+
+def all_reduce_sum(tensor, group):
+    """In-place sum over the ranks of a group (histogram reduction)."""
+    import torch.distributed as dist
+
+    if _needs_host_staging(tensor, group):
+        host = tensor.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        tensor.copy_(host)
+    else:
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
 
 
 def exchange_output_bands(accum, shard, group):
@@ -183,7 +216,7 @@ def exchange_output_bands(accum, shard, group):
             sl = shard.local(lo, hi, shard.accum_origin)
             send_buf = accum[(slice(None),) + sl].contiguous()
             if send_buf.numel():
-                ops.append(dist.P2POp(dist.isend, send_buf, nxt, group))
+                ops.append(("send", send_buf, nxt))
         if prv is not None:
             other = Shard(shard.plan, shard.grid, prv)
             lo, hi = other.band_box(axis)
@@ -191,7 +224,7 @@ def exchange_output_bands(accum, shard, group):
             shape = (accum.shape[0],) + tuple(b - a for a, b in zip(lo, hi))
             recv_buf = torch.empty(shape, dtype=accum.dtype, device=accum.device)
             if recv_buf.numel():
-                ops.append(dist.P2POp(dist.irecv, recv_buf, prv, group))
+                ops.append(("recv", recv_buf, prv))
         _p2p(ops, group)
         if recv_buf is not None and recv_buf.numel():
             accum[recv_sl] += recv_buf
@@ -246,11 +279,11 @@ def exchange_input_halo(core, shard, group):
         give = overlap(o_in_lo, o_in_hi, core_lo, core_hi)  # what peer reads from my core
         if give is not None:
             buf = core[shard.local(*give, core_lo)].contiguous()
-            ops.append(dist.P2POp(dist.isend, buf, peer, group))
+            ops.append(("send", buf, peer))
         if need is not None:
             shape = tuple(h - l for l, h in zip(*need))
             buf = torch.empty(shape, dtype=core.dtype, device=core.device)
-            ops.append(dist.P2POp(dist.irecv, buf, peer, group))
+            ops.append(("recv", buf, peer))
             pending.append((need, buf))
     _p2p(ops, group)
     for need, buf in pending:
@@ -296,7 +329,7 @@ def predict_shard(volume, model, plan, shard, n_channels=3, batch_size=16,
         )
 
         def reduce_fn(hist):
-            dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
+            all_reduce_sum(hist, group)
 
         mn, mx = inference.volume_percentiles(core, brightness_clip, normalization_percentiles,
                                               reduce_fn=reduce_fn)

@@ -95,13 +95,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; EXASPIM_DIST_BACKEND=gloo lets several ranks rehearse the
+    # sharded path on a single GPU (device index wraps, transfers staged via host)
+    backend = os.environ.get("EXASPIM_DIST_BACKEND", "nccl")
+    device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     group = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
         group = dist.group.WORLD
 
     # model: random-init weights of the reference architecture (no checkpoints offline)
@@ -162,7 +168,8 @@ def main():
     if group is not None:
         import torch.distributed as dist
 
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -191,7 +198,7 @@ def main():
             with open(tpath) as f:
                 kernels = json.load(f).get("kernels", {})
             tag = {"bf16": "BF16Tag", "fp16": "F16Tag", "fp32": "F32Tag"}[args.dtype]
-            entry = kernels.get(f"conv3x3x3_t14<{tag}, 4, 8, 16, 4, 1, 4, 1, 2, 8>")
+            entry = kernels.get(f"conv3x3x3_zcol<{tag}, 4, 8, 16, 4, 1, 1, 1, 2, 1, true, false>")
             if entry:
                 traffic = entry["hbm_bytes_per_launch"]
         result = {
@@ -220,7 +227,7 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "conv3x3x3_t14<4x8x16 tile, 32 couts> (the 96^3-level convs inc.3, up4.0, up4.3)",
+                "kernel": "conv3x3x3_zcol<4x8x16 tile, 32 couts> (the 96^3-level convs inc.3, up4.0, up4.3)",
                 "algorithmic_flop_per_launch": flops / launches if launches else None,
                 "achieved": achieved,
                 "peak": peak,
