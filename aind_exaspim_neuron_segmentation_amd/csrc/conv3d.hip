@@ -59,6 +59,20 @@ __device__ __forceinline__ void mma<F16Tag>(f32x16& acc, const uint4& wf, const 
                                                  __builtin_bit_cast(f16x8, xf), acc, 0, 0, 0);
 }
 
+// 16-byte buffer load with hardware range check: an offset at or beyond the
+// descriptor's size returns zeros, which is how the conv's zero padding (and
+// the tail of the staging list) is produced without branches.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOutOfRange = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // store 4 consecutive output channels of one voxel
 template <typename Tag>
 __device__ __forceinline__ void store4(void* dst, size_t elem_off, float a, float b, float c, float d);
@@ -338,16 +352,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
         } else {
             src = static_cast<const char*>(a.src_b); cs = a.cb; ch0 = c * KC - a.ca;
         }
-        const char* pbase = src + (size_t)nb * patch_vox * cs * ES;
+        const unsigned rowb = cs * ES;  // bytes of one voxel record of this source
+        const __amdgpu_buffer_rsrc_t rsrc =
+            make_rsrc(src + (size_t)nb * patch_vox * rowb, patch_vox * rowb);
 #pragma unroll
         for (int it = 0; it < NITEMS; ++it) {
             const int i = tid + it * NTHREADS;
-            const int kg = i >= HV ? 1 : 0;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (vidx[it] >= 0)
-                v = *reinterpret_cast<const uint4*>(
-                    pbase + ((size_t)(unsigned)vidx[it] * cs + ch0 + kg * G) * ES);
-            stg[it] = v;
+            const unsigned voff = vidx[it] >= 0 ? (unsigned)vidx[it] * rowb + (i >= HV ? 16u : 0u)
+                                                : kOutOfRange;
+            stg[it] = buf_load16(rsrc, voff, ch0 * ES);
         }
     };
     auto stage_store = [&]() {
@@ -407,6 +420,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
 
     // ---- epilogue: bias + LeakyReLU, transposed through LDS ------------------
     char* wl = reinterpret_cast<char*>(lds) + wave * (32 * RECB);
+    // bias first: a load inside the store loop would wait (vmcnt counts stores on
+    // gfx950) for every store issued before it
+    float4 bq[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            bq[nt][q] = *reinterpret_cast<const float4*>(a.bias + ntile0 * 32 + nt * 32 + 8 * q + 4 * half);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -414,7 +435,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int cl = nt * 32 + 8 * q + 4 * half;  // channel inside the slice
-                const float4 b = *reinterpret_cast<const float4*>(a.bias + ntile0 * 32 + cl);
+                const float4 b = bq[nt][q];
                 float v0 = acc[mt][nt][4 * q + 0] + b.x;
                 float v1 = acc[mt][nt][4 * q + 1] + b.y;
                 float v2 = acc[mt][nt][4 * q + 2] + b.z;
@@ -556,24 +577,25 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_zcol(
         } else {
             src = static_cast<const char*>(a.src_b); cs = a.cb; ch0 = c * KC - a.ca;
         }
-        const char* pbase = src + (size_t)nb * patch_vox * cs * ES;
+        const unsigned rowb = cs * ES;  // bytes of one voxel record of this source
+        const __amdgpu_buffer_rsrc_t rsrc =
+            make_rsrc(src + (size_t)nb * patch_vox * rowb, patch_vox * rowb);
 #pragma unroll
         for (int it = 0; it < NITEMS; ++it) {
             const int i = tid + it * NTHREADS;
-            const int kg = i >= HV ? 1 : 0;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (vidx[it] >= 0)
-                v = *reinterpret_cast<const uint4*>(
-                    pbase + ((size_t)(unsigned)vidx[it] * cs + ch0 + kg * G) * ES);
-            stg[it] = v;
+            const unsigned voff = vidx[it] >= 0 ? (unsigned)vidx[it] * rowb + (i >= HV ? 16u : 0u)
+                                                : kOutOfRange;
+            stg[it] = buf_load16(rsrc, voff, ch0 * ES);
         }
         if (WLDS) {
-            const uint4* wsrc = static_cast<const uint4*>(a.weights) + (size_t)c * 27 * ntiles * 64;
+            const __amdgpu_buffer_rsrc_t wrsrc =
+                make_rsrc(a.weights, (size_t)nchunks * 27 * ntiles * 1024);
 #pragma unroll
             for (int it = 0; it < WITEMS; ++it) {
                 const int i = tid + it * NTHREADS;
                 const int tap = i / (NT * 64), rest = i % (NT * 64);
-                if (i < WUNITS) stg[NITEMS + it] = wsrc[((size_t)tap * ntiles + ntile0) * 64 + rest];
+                const unsigned voff = i < WUNITS ? ((tap * ntiles + ntile0) * 64 + rest) * 16u : kOutOfRange;
+                stg[NITEMS + it] = buf_load16(wrsrc, voff, c * 27 * ntiles * 1024);
             }
         }
     };
@@ -655,6 +677,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_zcol(
 
     // ---- epilogue: bias + LeakyReLU, transposed through LDS ------------------
     char* wl = reinterpret_cast<char*>(lds) + wave * (32 * RECB);
+    float4 bq[NT][4];  // bias before the stores (vmcnt counts stores on gfx950)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            bq[nt][q] = *reinterpret_cast<const float4*>(a.bias + ntile0 * 32 + nt * 32 + 8 * q + 4 * half);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int j = mt / TZ, z = mt % TZ;
@@ -663,7 +691,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_zcol(
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int cl = nt * 32 + 8 * q + 4 * half;
-                const float4 b = *reinterpret_cast<const float4*>(a.bias + ntile0 * 32 + cl);
+                const float4 b = bq[nt][q];
                 float v0 = acc[mt][nt][4 * q + 0] + b.x;
                 float v1 = acc[mt][nt][4 * q + 1] + b.y;
                 float v2 = acc[mt][nt][4 * q + 2] + b.z;
@@ -717,6 +745,284 @@ static int launch_zcol(const ConvArgs& a, hipStream_t stream) {
     return EXASPIM_OK;
 }
 
+// ---- v5: persistent workgroups, one wave per SIMD ----------------------------
+// For the 32-cout layers (53 % of the network's FLOPs). One 256-thread
+// workgroup per CU walks a list of 4 x 8 x 32 tiles (1024 voxels; z-column
+// mapping: wave w owns rows 2w, 2w+1 of every plane -> 8 accumulator tiles).
+// Every (tile, chunk) step prefetches the NEXT step's halo pieces and weight
+// fragments global -> VGPR at its start -- also across tile boundaries -- so the
+// only exposed memory time is the very first step of a workgroup. A step's LDS
+// work is (6 x 2 x 9 fragment reads + 27 weight reads) per wave for 216 MFMAs,
+// about half of what the 512-voxel tiles need per FLOP, which is what bounds
+// those. launch_bounds(256, 1): the wave may use the whole 512-register file.
+template <typename Tag, int TY, int WGS_PER_CU>
+__global__ __launch_bounds__(256, WGS_PER_CU) void conv3x3x3_persist(ConvArgs a, int tiles_z, int tiles_y,
+                                                            int tiles_x, int total_tiles) {
+    constexpr int TZ = 4, TX = 32, YXW = TY / 4, NT = 1;
+    constexpr int G = Tag::kG;
+    constexpr int KC = 2 * G;
+    constexpr int ES = 16 / G;
+    constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+    constexpr int HV = HZ * HY * HX;
+    constexpr int NTHREADS = 256;
+    constexpr int MT = TZ * YXW;
+    constexpr int NITEMS = (2 * HV + NTHREADS - 1) / NTHREADS;   // 16
+    constexpr int WUNITS = 27 * 64;
+    constexpr int WITEMS = (WUNITS + NTHREADS - 1) / NTHREADS;   // 7
+    constexpr int RECB = NT * 32 * ES;
+    constexpr int XUNITS = 2 * HV;
+    constexpr int LDS_UNITS = XUNITS + WUNITS;
+
+    __shared__ __attribute__((aligned(16))) uint4 lds[LDS_UNITS];
+    uint4* const wlds = lds + XUNITS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int r = lane & 31;
+
+    // tile list: XCD k (workgroups b with b % 8 == k) takes a contiguous run of
+    // tiles, dealt to its workgroups round-robin so neighbours run concurrently
+    const int nwg = gridDim.x;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int wg_per_xcd = (nwg + 7 - xcd) >> 3;       // workgroups on this XCD
+    const int run_lo = (int)((long long)total_tiles * xcd / 8);
+    const int run_hi = (int)((long long)total_tiles * (xcd + 1) / 8);
+
+    const int ntiles = a.cout >> 5;
+    const int ntile0 = blockIdx.y;
+    const int nchunks = (a.ca + a.cb) / KC;
+    const size_t patch_vox = (size_t)a.d * a.h * a.w;
+
+    int col[YXW];
+#pragma unroll
+    for (int j = 0; j < YXW; ++j) {
+        const int p = (wave * YXW + j) * 32 + r;
+        col[j] = (p / TX) * HX + (p % TX) + half * HV;
+    }
+    // Staging item i = tid + it * 256 = channel group (i >= HV) of halo voxel
+    // (i mod HV). Tile-independent per item: its voxel offset relative to the
+    // tile origin and a mask of the tile faces it lies beyond (bits 0-5: low/high
+    // z, y, x; bit 6: past the end of the list; bit 7: second channel group).
+    int rel[NITEMS], iflag[NITEMS];
+#pragma unroll
+    for (int it = 0; it < NITEMS; ++it) {
+        const int i = tid + it * NTHREADS;
+        const int kg = i >= HV ? 1 : 0;
+        const int hv = i - kg * HV;
+        const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
+        rel[it] = ((hz - 1) * a.h + (hy - 1)) * a.w + (hx - 1);
+        iflag[it] = (hz == 0 ? 1 : 0) | (hz == HZ - 1 ? 2 : 0) | (hy == 0 ? 4 : 0) |
+                    (hy == HY - 1 ? 8 : 0) | (hx == 0 ? 16 : 0) | (hx == HX - 1 ? 32 : 0) |
+                    (i >= 2 * HV ? 64 : 0) | (kg << 7);
+    }
+    unsigned wvoff[WITEMS];  // byte offset of the thread's weight fragments inside a chunk
+#pragma unroll
+    for (int it = 0; it < WITEMS; ++it) {
+        const int i = tid + it * NTHREADS;
+        wvoff[it] = i < WUNITS ? (((i >> 6) * ntiles + ntile0) * 64 + (i & 63)) * 16u : kOutOfRange;
+    }
+    const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(a.weights, (size_t)nchunks * 27 * ntiles * 1024);
+
+    uint4 stg[NITEMS + WITEMS];
+    int tz0 = 0, ty0 = 0, tx0 = 0, tnb = 0;  // origin of the tile being prefetched
+
+    auto decode = [&](int tile, int& z0, int& y0, int& x0, int& nb) {
+        int t = tile;
+        x0 = (t % tiles_x) * TX; t /= tiles_x;
+        y0 = (t % tiles_y) * TY; t /= tiles_y;
+        z0 = (t % tiles_z) * TZ; t /= tiles_z;
+        nb = t;
+    };
+    auto stage_load = [&](int c) {
+        const char* src;
+        int cs, ch0;
+        if (c * KC < a.ca) {
+            src = static_cast<const char*>(a.src_a); cs = a.ca; ch0 = c * KC;
+        } else {
+            src = static_cast<const char*>(a.src_b); cs = a.cb; ch0 = c * KC - a.ca;
+        }
+        const unsigned rowb = cs * ES;
+        const __amdgpu_buffer_rsrc_t rsrc =
+            make_rsrc(src + (size_t)tnb * patch_vox * rowb, patch_vox * rowb);
+        // faces of the volume this tile touches (tiles are exact: w % 32 == 0 etc.)
+        const int tflag = (tz0 == 0 ? 1 : 0) | (tz0 + TZ >= a.d ? 2 : 0) | (ty0 == 0 ? 4 : 0) |
+                          (ty0 + TY >= a.h ? 8 : 0) | (tx0 == 0 ? 16 : 0) |
+                          (tx0 + TX >= a.w ? 32 : 0) | 64;
+        const int origin = (tz0 * a.h + ty0) * a.w + tx0;
+#pragma unroll
+        for (int it = 0; it < NITEMS; ++it) {
+            const unsigned voff = (iflag[it] & tflag)
+                                      ? kOutOfRange
+                                      : (unsigned)(origin + rel[it]) * rowb + ((iflag[it] >> 3) & 16u);
+            stg[it] = buf_load16(rsrc, voff, ch0 * ES);
+        }
+#pragma unroll
+        for (int it = 0; it < WITEMS; ++it)
+            stg[NITEMS + it] = buf_load16(wrsrc, wvoff[it], c * 27 * ntiles * 1024);
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int it = 0; it < NITEMS; ++it) {
+            const int i = tid + it * NTHREADS;
+            if (i < 2 * HV) lds[i] = stg[it];
+        }
+#pragma unroll
+        for (int it = 0; it < WITEMS; ++it) {
+            const int i = tid + it * NTHREADS;
+            if (i < WUNITS) wlds[i] = stg[NITEMS + it];
+        }
+    };
+
+    int tile = run_lo + jx;
+    if (tile >= run_hi) return;
+    // stagger the second workgroup of each CU so the two do not run their MFMA
+    // and their epilogue phases in lockstep (a.debug = number of ~4 us sleeps)
+    if (WGS_PER_CU > 1 && (int)blockIdx.x >= (int)gridDim.x / 2)
+        for (int i = 0; i < a.debug; ++i) __builtin_amdgcn_s_sleep(127);
+    decode(tile, tz0, ty0, tx0, tnb);
+    stage_load(0);
+    stage_store();
+    __syncthreads();
+
+    float4 bq[4];  // this lane's 16 bias values, loaded once (never between stores)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        bq[q] = *reinterpret_cast<const float4*>(a.bias + ntile0 * 32 + 8 * q + 4 * half);
+
+    f32x16 acc[MT];
+    int cz0 = tz0, cy0 = ty0, cx0 = tx0, cnb = tnb;  // tile being computed
+    int c = 0;
+    for (;;) {
+        if (c == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+        }
+        // ---- prefetch the next step -------------------------------------------
+        const bool last_chunk = c + 1 == nchunks;
+        const int next_tile = last_chunk ? tile + wg_per_xcd : tile;
+        const bool has_next = next_tile < run_hi;
+        if (has_next) {
+            if (last_chunk) decode(next_tile, tz0, ty0, tx0, tnb);
+            stage_load(last_chunk ? 0 : c + 1);
+        }
+        // ---- this step's 216 MFMAs ----------------------------------------------
+        // Software-pipelined over the 18 (in-plane tap g, column j) groups: the six
+        // plane fragments (and, per tap, the three weight fragments) of group k+1
+        // are issued before the 12 MFMAs of group k; the scheduling fences keep
+        // hipcc from re-serialising read -> wait -> MFMA on one register set.
+        uint4 xf[2][HZ];
+        uint4 wf[2][3];
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz) wf[0][dz] = wlds[(dz * 9) * 64 + lane];
+#pragma unroll
+        for (int zin = 0; zin < HZ; ++zin) xf[0][zin] = lds[col[0] + zin * HY * HX];
+#pragma unroll
+        for (int k = 0; k < 9 * YXW; ++k) {
+            const int g = k / YXW, j = k % YXW;
+            if (k + 1 < 9 * YXW) {
+                const int g1 = (k + 1) / YXW, j1 = (k + 1) % YXW;
+                const int goff1 = (g1 / 3) * HX + g1 % 3;
+                if (j1 == 0) {
+#pragma unroll
+                    for (int dz = 0; dz < 3; ++dz)
+                        wf[g1 & 1][dz] = wlds[(dz * 9 + g1) * 64 + lane];
+                }
+#pragma unroll
+                for (int zin = 0; zin < HZ; ++zin)
+                    xf[(k + 1) & 1][zin] = lds[col[j1] + zin * HY * HX + goff1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int zin = 0; zin < HZ; ++zin)
+#pragma unroll
+                for (int dz = 0; dz < 3; ++dz) {
+                    const int z = zin - dz;
+                    if (z >= 0 && z < TZ) mma<Tag>(acc[j * TZ + z], wf[g & 1][dz], xf[k & 1][zin]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();  // all waves are done reading this step's LDS image
+        if (last_chunk) {
+            // ---- epilogue of the finished tile: bias + LeakyReLU, through LDS ------
+            char* wl = reinterpret_cast<char*>(lds) + wave * (32 * RECB);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int j = mt / TZ, z = mt % TZ;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cl = 8 * q + 4 * half;
+                    const float4 b = bq[q];
+                    float v0 = acc[mt][4 * q + 0] + b.x;
+                    float v1 = acc[mt][4 * q + 1] + b.y;
+                    float v2 = acc[mt][4 * q + 2] + b.z;
+                    float v3 = acc[mt][4 * q + 3] + b.w;
+                    v0 = v0 > 0.f ? v0 : v0 * a.slope;
+                    v1 = v1 > 0.f ? v1 : v1 * a.slope;
+                    v2 = v2 > 0.f ? v2 : v2 * a.slope;
+                    v3 = v3 > 0.f ? v3 : v3 * a.slope;
+                    store4<Tag>(wl, (size_t)(r * RECB) / ES + cl, v0, v1, v2, v3);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                constexpr int PPV = RECB / 16;
+                constexpr int ROUNDS = 32 * PPV / 64;
+#pragma unroll
+                for (int k = 0; k < ROUNDS; ++k) {
+                    const int p = k * 64 + lane;
+                    const int vv = p / PPV, part = p % PPV;
+                    const int pos = (wave * YXW + j) * 32 + vv;
+                    const int gz = cz0 + z, gy = cy0 + pos / TX, gx = cx0 + pos % TX;
+                    const uint4 val = *reinterpret_cast<const uint4*>(wl + p * 16);
+                    if (gz < a.d && gy < a.h && gx < a.w) {
+                        const size_t vox = (((size_t)cnb * a.d + gz) * a.h + gy) * a.w + gx;
+                        *reinterpret_cast<uint4*>(static_cast<char*>(a.dst) +
+                                                  (vox * a.cout + ntile0 * 32) * ES + part * 16) = val;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            __syncthreads();  // the transposition buffers alias the LDS image
+        }
+        if (!has_next) break;
+        stage_store();
+        __syncthreads();
+        if (last_chunk) {
+            tile = next_tile; c = 0;
+            cz0 = tz0; cy0 = ty0; cx0 = tx0; cnb = tnb;
+        } else {
+            ++c;
+        }
+    }
+}
+
+template <typename Tag, int TY, int WGS_PER_CU>
+static int launch_persist(const ConvArgs& a, hipStream_t stream) {
+    const int tz = (a.d + 3) / 4, ty = (a.h + TY - 1) / TY, tx = (a.w + 31) / 32;
+    const long long total = (long long)tz * ty * tx * a.n;
+    if (total <= 0 || total > 0x7fffffffLL) {
+        set_error("conv: %lld tiles out of range", total);
+        return EXASPIM_E_INVALID;
+    }
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        EXA_CHECK_HIP(hipGetDevice(&dev));
+        EXA_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+        ncu = prop.multiProcessorCount;
+    }
+    const int nwg = (int)(total < ncu * WGS_PER_CU ? total : ncu * WGS_PER_CU);
+    dim3 grid(nwg, a.cout / 32);
+    conv3x3x3_persist<Tag, TY, WGS_PER_CU><<<grid, 256, 0, stream>>>(a, tz, ty, tx, (int)total);
+    EXA_CHECK_HIP(hipGetLastError());
+    return EXASPIM_OK;
+}
+
 // ---- host side: pick a tile configuration per layer -----------------------
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -755,6 +1061,8 @@ static int launch_typed(const ConvArgs& a, hipStream_t stream) {
         // z-column tiles, weights shared through LDS, one 32-cout slice per workgroup
         if (a.cout % 64 != 0) {
             if (l0_variant == 1) return launch_cfg<Tag, 4, 8, 16, 4, 1, 4, 1, 2, 8>(a, stream);
+            if (l0_variant == 2 && a.w % 32 == 0) return launch_persist<Tag, 8, 1>(a, stream);
+            if (l0_variant == 3 && a.w % 32 == 0) return launch_persist<Tag, 4, 2>(a, stream);
             return launch_zcol<Tag, 4, 8, 16, 4, 1, 1, 1, 2, 1, true, false>(a, stream);
         }
         if (l1_variant == 1) return launch_zcol<Tag, 4, 8, 16, 4, 1, 1, 1, 2, 1, true, false>(a, stream);

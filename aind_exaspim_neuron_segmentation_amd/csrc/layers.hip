@@ -126,64 +126,84 @@ __global__ __launch_bounds__(256) void conv_first_kernel(
         for (int mt = 0; mt < MT; ++mt)
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[ks], xv[mt][ks], acc[mt], 0, 0, 0);
 
+    // epilogue: bias + LeakyReLU, then through LDS so that each store instruction
+    // writes whole 16-byte pieces of consecutive voxel records
     constexpr int G = T::kG;
+    constexpr int ES = 16 / G;
+    constexpr int RECB = 32 * ES;           // bytes of one voxel's 32-channel slice
+    constexpr int PPV = RECB / 16;
+    __shared__ __attribute__((aligned(16))) char tr[4 * 32 * RECB];
+    char* wl = tr + wave * (32 * RECB);
+    float4 bq[4];  // bias before the stores (vmcnt counts stores on gfx950)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        bq[q] = *reinterpret_cast<const float4*>(bias + co_tile + 8 * q + 4 * half);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int v = v0 + mt * 32 + r;
-        if (v >= nvox) continue;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int co = co_tile + 8 * q + 4 * half;
-            const float4 b = *reinterpret_cast<const float4*>(bias + co);
+            const int cl = 8 * q + 4 * half;
+            const float4 b = bq[q];
             float o[4] = {acc[mt][4 * q] + b.x, acc[mt][4 * q + 1] + b.y,
                           acc[mt][4 * q + 2] + b.z, acc[mt][4 * q + 3] + b.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = o[j] > 0.f ? o[j] : o[j] * slope;
-            char* out = static_cast<char*>(dst) + ((size_t)v * c0p + co) * (16 / G);
+            char* slot = wl + r * RECB + cl * ES;
             if (G == 4) {
-                *reinterpret_cast<float4*>(out) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4*>(slot) = make_float4(o[0], o[1], o[2], o[3]);
             } else {
                 float o8[8] = {o[0], o[1], o[2], o[3], 0.f, 0.f, 0.f, 0.f};
                 const uint4 pk = T::pack(o8);
-                *reinterpret_cast<uint2*>(out) = make_uint2(pk.x, pk.y);
+                *reinterpret_cast<uint2*>(slot) = make_uint2(pk.x, pk.y);
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 32 * PPV / 64; ++k) {
+            const int p = k * 64 + lane;
+            const int v = v0 + mt * 32 + p / PPV;
+            const uint4 val = *reinterpret_cast<const uint4*>(wl + p * 16);
+            if (v < nvox)
+                *reinterpret_cast<uint4*>(static_cast<char*>(dst) +
+                                          ((size_t)v * c0p + co_tile) * ES + (p % PPV) * 16) = val;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
 // ---- max-pool 2x2x2 ----------------------------------------------------------
+// Grid: x = 16-byte pieces of one output row, y = output row, z = patch * depth.
+// All per-thread index arithmetic is 32-bit; the row/plane split is scalar.
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool2_kernel(const uint4* __restrict__ src,
-                                                       uint4* __restrict__ dst, int n, int d,
-                                                       int h, int w, int cg) {
+__global__ __launch_bounds__(64) void maxpool2_kernel(const uint4* __restrict__ src,
+                                                      uint4* __restrict__ dst, int d, int h,
+                                                      int w, int cg) {
     // d,h,w: input size; cg: 16-byte groups per voxel
     const int od = d / 2, oh = h / 2, ow = w / 2;
-    const size_t total = (size_t)n * od * oh * ow * cg;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (size_t)gridDim.x * blockDim.x) {
-        const int g = (int)(i % cg);
-        size_t t = i / cg;
-        const int x = (int)(t % ow); t /= ow;
-        const int y = (int)(t % oh); t /= oh;
-        const int z = (int)(t % od);
-        const size_t nb = t / od;
-        float m[T::kG];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // piece inside the output row
+    if (i >= ow * cg) return;
+    const int x = i / cg, g = i - x * cg;
+    const int y = blockIdx.y;
+    const int nb = blockIdx.z / od, z = blockIdx.z - nb * od;
+    float m[T::kG];
 #pragma unroll
-        for (int j = 0; j < T::kG; ++j) m[j] = -INFINITY;
+    for (int j = 0; j < T::kG; ++j) m[j] = -INFINITY;
+    const size_t plane = (size_t)h * w;
+    const uint4* base = src + (((size_t)nb * d + 2 * z) * plane + (size_t)(2 * y) * w + 2 * x) * cg + g;
 #pragma unroll
-        for (int dz = 0; dz < 2; ++dz)
+    for (int dz = 0; dz < 2; ++dz)
 #pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
+        for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    const size_t vox = ((nb * d + 2 * z + dz) * h + 2 * y + dy) * w + 2 * x + dx;
-                    float f[T::kG];
-                    T::unpack(src[vox * cg + g], f);
+            for (int dx = 0; dx < 2; ++dx) {
+                float f[T::kG];
+                T::unpack(base[(dz * plane + (size_t)dy * w + dx) * cg], f);
 #pragma unroll
-                    for (int j = 0; j < T::kG; ++j) m[j] = fmaxf(m[j], f[j]);
-                }
-        dst[i] = T::pack(m);
-    }
+                for (int j = 0; j < T::kG; ++j) m[j] = fmaxf(m[j], f[j]);
+            }
+    dst[((((size_t)nb * od + z) * oh + y) * ow + x) * cg + g] = T::pack(m);
 }
 
 // ---- trilinear x2, align_corners=True ---------------------------------------
@@ -198,45 +218,44 @@ __device__ __forceinline__ void lerp_coord(int o, int in, int out, int& i0, int&
     l1 = fminf(fmaxf(s - (float)i0, 0.f), 1.f);
 }
 
+// Same grid shape as the pool: the z and y interpolation coordinates are scalar.
 template <typename T>
-__global__ __launch_bounds__(256) void upsample2_kernel(const uint4* __restrict__ src,
-                                                        uint4* __restrict__ dst, int n, int d,
-                                                        int h, int w, int cg) {
+__global__ __launch_bounds__(128) void upsample2_kernel(const uint4* __restrict__ src,
+                                                        uint4* __restrict__ dst, int d, int h,
+                                                        int w, int cg) {
     const int od = d * 2, oh = h * 2, ow = w * 2;
-    const size_t total = (size_t)n * od * oh * ow * cg;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (size_t)gridDim.x * blockDim.x) {
-        const int g = (int)(i % cg);
-        size_t t = i / cg;
-        const int x = (int)(t % ow); t /= ow;
-        const int y = (int)(t % oh); t /= oh;
-        const int z = (int)(t % od);
-        const size_t nb = t / od;
-        int z0, z1, y0, y1, x0, x1;
-        float lz, ly, lx;
-        lerp_coord(z, d, od, z0, z1, lz);
-        lerp_coord(y, h, oh, y0, y1, ly);
-        lerp_coord(x, w, ow, x0, x1, lx);
-        float acc[T::kG];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ow * cg) return;
+    const int x = i / cg, g = i - x * cg;
+    const int y = blockIdx.y;
+    const int nb = blockIdx.z / od, z = blockIdx.z - nb * od;
+    int z0, z1, y0, y1, x0, x1;
+    float lz, ly, lx;
+    lerp_coord(z, d, od, z0, z1, lz);
+    lerp_coord(y, h, oh, y0, y1, ly);
+    lerp_coord(x, w, ow, x0, x1, lx);
+    float acc[T::kG];
 #pragma unroll
-        for (int j = 0; j < T::kG; ++j) acc[j] = 0.f;
-        const int zs[2] = {z0, z1}, ys[2] = {y0, y1}, xs[2] = {x0, x1};
-        const float wz[2] = {1.f - lz, lz}, wy[2] = {1.f - ly, ly}, wx[2] = {1.f - lx, lx};
+    for (int j = 0; j < T::kG; ++j) acc[j] = 0.f;
+    const int zs[2] = {z0, z1}, ys[2] = {y0, y1}, xs[2] = {x0, x1};
+    const float wz[2] = {1.f - lz, lz}, wy[2] = {1.f - ly, ly}, wx[2] = {1.f - lx, lx};
+    const uint4* base = src + (size_t)nb * d * h * w * cg + g;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b) {
+            const uint4* row = base + ((size_t)zs[a] * h + ys[b]) * w * cg;
+            const float wzy = wz[a] * wy[b];
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const size_t vox = ((nb * d + zs[a]) * h + ys[b]) * w + xs[c];
-                    float f[T::kG];
-                    T::unpack(src[vox * cg + g], f);
-                    const float wgt = wz[a] * wy[b] * wx[c];
+            for (int c = 0; c < 2; ++c) {
+                float f[T::kG];
+                T::unpack(row[xs[c] * cg], f);
+                const float wgt = wzy * wx[c];
 #pragma unroll
-                    for (int j = 0; j < T::kG; ++j) acc[j] = fmaf(wgt, f[j], acc[j]);
-                }
-        dst[i] = T::pack(acc);
-    }
+                for (int j = 0; j < T::kG; ++j) acc[j] = fmaf(wgt, f[j], acc[j]);
+            }
+        }
+    dst[((((size_t)nb * od + z) * oh + y) * ow + x) * cg + g] = T::pack(acc);
 }
 
 // ---- head: 1x1x1 conv (+ sigmoid), channels-last -> NCDHW float32 -----------
@@ -244,31 +263,30 @@ template <typename T, int OC>
 __global__ __launch_bounds__(256) void head_kernel(const uint4* __restrict__ src,
                                                    const float* __restrict__ w,
                                                    const float* __restrict__ bias,
-                                                   float* __restrict__ out, size_t nvox_per_patch,
-                                                   int n, int c0p, int apply_sigmoid) {
-    const size_t total = nvox_per_patch * n;
+                                                   float* __restrict__ out, unsigned nvox_per_patch,
+                                                   int c0p, int apply_sigmoid) {
+    const unsigned sp = blockIdx.x * blockDim.x + threadIdx.x;  // voxel inside the patch
+    if (sp >= nvox_per_patch) return;
+    const unsigned nb = blockIdx.y;
     const int cg = c0p / T::kG;
-    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < total;
-         v += (size_t)gridDim.x * blockDim.x) {
-        float acc[OC];
+    const uint4* rec = src + ((size_t)nb * nvox_per_patch + sp) * cg;
+    float acc[OC];
 #pragma unroll
-        for (int o = 0; o < OC; ++o) acc[o] = bias[o];
-        for (int g = 0; g < cg; ++g) {
-            float f[T::kG];
-            T::unpack(src[v * cg + g], f);
+    for (int o = 0; o < OC; ++o) acc[o] = bias[o];
+    for (int g = 0; g < cg; ++g) {
+        float f[T::kG];
+        T::unpack(rec[g], f);
 #pragma unroll
-            for (int o = 0; o < OC; ++o)
+        for (int o = 0; o < OC; ++o)
 #pragma unroll
-                for (int j = 0; j < T::kG; ++j)
-                    acc[o] = fmaf(f[j], w[o * c0p + g * T::kG + j], acc[o]);
-        }
-        const size_t nb = v / nvox_per_patch, sp = v % nvox_per_patch;
+            for (int j = 0; j < T::kG; ++j)
+                acc[o] = fmaf(f[j], w[o * c0p + g * T::kG + j], acc[o]);
+    }
 #pragma unroll
-        for (int o = 0; o < OC; ++o) {
-            float r = acc[o];
-            if (apply_sigmoid) r = 1.f / (1.f + expf(-r));
-            out[(nb * OC + o) * nvox_per_patch + sp] = r;
-        }
+    for (int o = 0; o < OC; ++o) {
+        float r = acc[o];
+        if (apply_sigmoid) r = 1.f / (1.f + expf(-r));
+        out[((size_t)nb * OC + o) * nvox_per_patch + sp] = r;
     }
 }
 
@@ -303,9 +321,11 @@ int launch_maxpool2(int dtype, const void* src, void* dst, int n, int d, int h, 
                     int c, hipStream_t stream) {
     EXA_CHECK_ARG(d % 2 == 0 && h % 2 == 0 && w % 2 == 0, "maxpool: odd size %dx%dx%d", d, h, w);
     const int cg = c * dtype_size(dtype) / 16;
-    const size_t total = (size_t)n * (d / 2) * (h / 2) * (w / 2) * cg;
-    DISPATCH_T(dtype, (maxpool2_kernel<T><<<stream_grid(total), 256, 0, stream>>>(
-                          static_cast<const uint4*>(src), static_cast<uint4*>(dst), n, d, h, w, cg)));
+    const int row = (w / 2) * cg;
+    EXA_CHECK_ARG((long long)n * (d / 2) <= 65535 && h / 2 <= 65535, "maxpool: grid too large");
+    dim3 grid((row + 63) / 64, h / 2, n * (d / 2));
+    DISPATCH_T(dtype, (maxpool2_kernel<T><<<grid, 64, 0, stream>>>(
+                          static_cast<const uint4*>(src), static_cast<uint4*>(dst), d, h, w, cg)));
     EXA_CHECK_HIP(hipGetLastError());
     return EXASPIM_OK;
 }
@@ -313,9 +333,11 @@ int launch_maxpool2(int dtype, const void* src, void* dst, int n, int d, int h, 
 int launch_upsample2(int dtype, const void* src, void* dst, int n, int d, int h, int w,
                      int c, hipStream_t stream) {
     const int cg = c * dtype_size(dtype) / 16;
-    const size_t total = (size_t)n * d * h * w * 8 * cg;
-    DISPATCH_T(dtype, (upsample2_kernel<T><<<stream_grid(total), 256, 0, stream>>>(
-                          static_cast<const uint4*>(src), static_cast<uint4*>(dst), n, d, h, w, cg)));
+    const int row = (w * 2) * cg;
+    EXA_CHECK_ARG((long long)n * d * 2 <= 65535 && h * 2 <= 65535, "upsample: grid too large");
+    dim3 grid((row + 127) / 128, h * 2, n * d * 2);
+    DISPATCH_T(dtype, (upsample2_kernel<T><<<grid, 128, 0, stream>>>(
+                          static_cast<const uint4*>(src), static_cast<uint4*>(dst), d, h, w, cg)));
     EXA_CHECK_HIP(hipGetLastError());
     return EXASPIM_OK;
 }
@@ -323,13 +345,15 @@ int launch_upsample2(int dtype, const void* src, void* dst, int n, int d, int h,
 template <typename T>
 static int launch_head_t(const void* src, const float* w, const float* bias, float* out,
                          size_t nvox, int n, int c0p, int oc, int sig, hipStream_t stream) {
-    const unsigned grid = stream_grid(nvox * n);
+    EXA_CHECK_ARG(nvox < 0x7fffffffULL && n <= 65535, "head: patch too large");
+    dim3 grid((unsigned)((nvox + 255) / 256), n);
     const uint4* s = static_cast<const uint4*>(src);
+    const unsigned nv = (unsigned)nvox;
     switch (oc) {
-        case 1: head_kernel<T, 1><<<grid, 256, 0, stream>>>(s, w, bias, out, nvox, n, c0p, sig); break;
-        case 2: head_kernel<T, 2><<<grid, 256, 0, stream>>>(s, w, bias, out, nvox, n, c0p, sig); break;
-        case 3: head_kernel<T, 3><<<grid, 256, 0, stream>>>(s, w, bias, out, nvox, n, c0p, sig); break;
-        case 4: head_kernel<T, 4><<<grid, 256, 0, stream>>>(s, w, bias, out, nvox, n, c0p, sig); break;
+        case 1: head_kernel<T, 1><<<grid, 256, 0, stream>>>(s, w, bias, out, nv, c0p, sig); break;
+        case 2: head_kernel<T, 2><<<grid, 256, 0, stream>>>(s, w, bias, out, nv, c0p, sig); break;
+        case 3: head_kernel<T, 3><<<grid, 256, 0, stream>>>(s, w, bias, out, nv, c0p, sig); break;
+        case 4: head_kernel<T, 4><<<grid, 256, 0, stream>>>(s, w, bias, out, nv, c0p, sig); break;
         default: set_error("head: out_channels %d unsupported", oc); return EXASPIM_E_INVALID;
     }
     EXA_CHECK_HIP(hipGetLastError());

@@ -119,41 +119,36 @@ template <> __device__ __forceinline__ double load_voxel<EXASPIM_VOX_U16>(const 
 template <> __device__ __forceinline__ double load_voxel<EXASPIM_VOX_I16>(const void* v, size_t i) { return (double)static_cast<const int16_t*>(v)[i]; }
 template <> __device__ __forceinline__ double load_voxel<EXASPIM_VOX_F32>(const void* v, size_t i) { return (double)static_cast<const float*>(v)[i]; }
 
+// Grid: x = voxels of one patch row, y = patch row, z = patch * depth.
 template <int VOX>
-__global__ __launch_bounds__(256) void gather_kernel(const void* __restrict__ vol,
+__global__ __launch_bounds__(128) void gather_kernel(const void* __restrict__ vol,
                                                      exaspim_block blk,
-                                                     const int* __restrict__ starts, int n, int pz,
+                                                     const int* __restrict__ starts, int pz,
                                                      int py, int px, double clip, int has_clip,
                                                      double mn, double denom,
                                                      float* __restrict__ out) {
-    const size_t pvox = (size_t)pz * py * px;
-    const size_t total = pvox * n;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (size_t)gridDim.x * blockDim.x) {
-        const int p = (int)(i / pvox);
-        size_t t = i % pvox;
-        const int x = (int)(t % px); t /= px;
-        const int y = (int)(t % py);
-        const int z = (int)(t / py);
-        const int sz = starts[3 * p], sy = starts[3 * p + 1], sx = starts[3 * p + 2];
-        // in-volume extent of the patch (img_util.py:424-428), then reflect
-        const int nz = min(sz + pz, blk.global[0]) - sz;
-        const int ny = min(sy + py, blk.global[1]) - sy;
-        const int nx = min(sx + px, blk.global[2]) - sx;
-        const int lz = sz + reflect_index(z, nz) - blk.origin[0];
-        const int ly = sy + reflect_index(y, ny) - blk.origin[1];
-        const int lx = sx + reflect_index(x, nx) - blk.origin[2];
-        float r = 0.f;
-        if ((unsigned)lz < (unsigned)blk.dims[0] && (unsigned)ly < (unsigned)blk.dims[1] &&
-            (unsigned)lx < (unsigned)blk.dims[2]) {
-            double v = load_voxel<VOX>(vol, ((size_t)lz * blk.dims[1] + ly) * blk.dims[2] + lx);
-            if (has_clip) v = fmin(v, clip);
-            double q = (v - mn) / denom;         // float64, like numpy (img_util.py:527)
-            q = fmin(fmax(q, 0.0), 1.0);         // np.clip(img, 0, 1)
-            r = (float)q;                        // cast on assignment (inference.py:191)
-        }
-        out[i] = r;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= px) return;
+    const int y = blockIdx.y;
+    const int p = blockIdx.z / pz, z = blockIdx.z - p * pz;
+    const int sz = starts[3 * p], sy = starts[3 * p + 1], sx = starts[3 * p + 2];
+    // in-volume extent of the patch (img_util.py:424-428), then reflect
+    const int nz = min(sz + pz, blk.global[0]) - sz;
+    const int ny = min(sy + py, blk.global[1]) - sy;
+    const int nx = min(sx + px, blk.global[2]) - sx;
+    const int lz = sz + reflect_index(z, nz) - blk.origin[0];
+    const int ly = sy + reflect_index(y, ny) - blk.origin[1];
+    const int lx = sx + reflect_index(x, nx) - blk.origin[2];
+    float r = 0.f;
+    if ((unsigned)lz < (unsigned)blk.dims[0] && (unsigned)ly < (unsigned)blk.dims[1] &&
+        (unsigned)lx < (unsigned)blk.dims[2]) {
+        double v = load_voxel<VOX>(vol, ((size_t)lz * blk.dims[1] + ly) * blk.dims[2] + lx);
+        if (has_clip) v = fmin(v, clip);
+        double q = (v - mn) / denom;         // float64, like numpy (img_util.py:527)
+        q = fmin(fmax(q, 0.0), 1.0);         // np.clip(img, 0, 1)
+        r = (float)q;                        // cast on assignment (inference.py:191)
     }
+    out[(((size_t)p * pz + z) * py + y) * px + x] = r;
 }
 
 // ------------------------------------------------------------------- stitch --
@@ -170,53 +165,45 @@ __device__ __forceinline__ bool covered(const int* s, const exaspim_window& w, c
            x < min(x0 + ox, g[2]);
 }
 
+// Grid: x = voxels of one trimmed output row, y = row, z = patch * trimmed depth.
 template <int C>
-__global__ __launch_bounds__(256) void stitch_kernel(const float* __restrict__ pred,
+__global__ __launch_bounds__(128) void stitch_kernel(const float* __restrict__ pred,
                                                      const int* __restrict__ starts, int n,
                                                      exaspim_window win,
                                                      float* __restrict__ accum,
                                                      exaspim_block blk) {
-    const int oz = win.patch[0] - 2 * win.trim, oy = win.patch[1] - 2 * win.trim,
-              ox = win.patch[2] - 2 * win.trim;
-    const size_t ovox = (size_t)oz * oy * ox;
+    const int oz = win.patch[0] - 2 * win.trim, ox = win.patch[2] - 2 * win.trim;
     const size_t pvox = (size_t)win.patch[0] * win.patch[1] * win.patch[2];
     const size_t avox = (size_t)blk.dims[0] * blk.dims[1] * blk.dims[2];
-    const size_t total = ovox * n;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (size_t)gridDim.x * blockDim.x) {
-        const int p = (int)(i / ovox);
-        size_t t = i % ovox;
-        const int x = (int)(t % ox); t /= ox;
-        const int y = (int)(t % oy);
-        const int z = (int)(t / oy);
-        const int* sp = starts + 3 * p;
-        const int gz = sp[0] + win.trim + z, gy = sp[1] + win.trim + y, gx = sp[2] + win.trim + x;
-        if (gz >= blk.global[0] || gy >= blk.global[1] || gx >= blk.global[2]) continue;
-        const int lz = gz - blk.origin[0], ly = gy - blk.origin[1], lx = gx - blk.origin[2];
-        if ((unsigned)lz >= (unsigned)blk.dims[0] || (unsigned)ly >= (unsigned)blk.dims[1] ||
-            (unsigned)lx >= (unsigned)blk.dims[2])
-            continue;
-        // The first patch of the batch that covers this voxel owns it and adds
-        // every covering patch in batch order (= the reference's loop order).
-        bool owner = true;
-        for (int j = 0; j < p; ++j)
-            if (covered(starts + 3 * j, win, blk.global, gz, gy, gx)) { owner = false; break; }
-        if (!owner) continue;
-        const size_t a = ((size_t)lz * blk.dims[1] + ly) * blk.dims[2] + lx;
-        float s[C];
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= ox) return;
+    const int y = blockIdx.y;
+    const int p = blockIdx.z / oz, z = blockIdx.z - p * oz;
+    const int* sp = starts + 3 * p;
+    const int gz = sp[0] + win.trim + z, gy = sp[1] + win.trim + y, gx = sp[2] + win.trim + x;
+    if (gz >= blk.global[0] || gy >= blk.global[1] || gx >= blk.global[2]) return;
+    const int lz = gz - blk.origin[0], ly = gy - blk.origin[1], lx = gx - blk.origin[2];
+    if ((unsigned)lz >= (unsigned)blk.dims[0] || (unsigned)ly >= (unsigned)blk.dims[1] ||
+        (unsigned)lx >= (unsigned)blk.dims[2])
+        return;
+    // The first patch of the batch that covers this voxel owns it and adds
+    // every covering patch in batch order (= the reference's loop order).
+    for (int j = 0; j < p; ++j)
+        if (covered(starts + 3 * j, win, blk.global, gz, gy, gx)) return;
+    const size_t a = ((size_t)lz * blk.dims[1] + ly) * blk.dims[2] + lx;
+    float s[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) s[c] = accum[c * avox + a];
-        for (int j = p; j < n; ++j) {
-            const int* sj = starts + 3 * j;
-            if (j != p && !covered(sj, win, blk.global, gz, gy, gx)) continue;
-            const int pz = gz - sj[0], py = gy - sj[1], px = gx - sj[2];
-            const size_t o = ((size_t)pz * win.patch[1] + py) * win.patch[2] + px;
+    for (int c = 0; c < C; ++c) s[c] = accum[c * avox + a];
+    for (int j = p; j < n; ++j) {
+        const int* sj = starts + 3 * j;
+        if (j != p && !covered(sj, win, blk.global, gz, gy, gx)) continue;
+        const int pz = gz - sj[0], py = gy - sj[1], px = gx - sj[2];
+        const size_t o = ((size_t)pz * win.patch[1] + py) * win.patch[2] + px;
 #pragma unroll
-            for (int c = 0; c < C; ++c) s[c] += pred[((size_t)j * C + c) * pvox + o];
-        }
-#pragma unroll
-        for (int c = 0; c < C; ++c) accum[c * avox + a] = s[c];
+        for (int c = 0; c < C; ++c) s[c] += pred[((size_t)j * C + c) * pvox + o];
     }
+#pragma unroll
+    for (int c = 0; c < C; ++c) accum[c * avox + a] = s[c];
 }
 
 // number of patch starts along one axis whose trimmed output covers g
@@ -238,23 +225,21 @@ __device__ __forceinline__ int axis_count(int g, int dim, int patch, int overlap
     return cnt;
 }
 
+// Grid: x = voxels of one row, y = row, z = plane; the z and y counts are scalar.
 __global__ __launch_bounds__(256) void finalize_kernel(float* __restrict__ accum, int channels,
                                                        exaspim_window win, exaspim_block blk) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= blk.dims[2]) return;
+    const int y = blockIdx.y, z = blockIdx.z;
     const size_t avox = (size_t)blk.dims[0] * blk.dims[1] * blk.dims[2];
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < avox;
-         i += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % blk.dims[2]);
-        size_t t = i / blk.dims[2];
-        const int y = (int)(t % blk.dims[1]);
-        const int z = (int)(t / blk.dims[1]);
-        const int cz = axis_count(z + blk.origin[0], blk.global[0], win.patch[0], win.overlap[0], win.trim);
-        const int cy = axis_count(y + blk.origin[1], blk.global[1], win.patch[1], win.overlap[1], win.trim);
-        const int cx = axis_count(x + blk.origin[2], blk.global[2], win.patch[2], win.overlap[2], win.trim);
-        const int cnt = cz * cy * cx;
-        if (cnt > 1) {
-            const float wgt = (float)cnt;
-            for (int c = 0; c < channels; ++c) accum[c * avox + i] = __fdiv_rn(accum[c * avox + i], wgt);
-        }
+    const int cz = axis_count(z + blk.origin[0], blk.global[0], win.patch[0], win.overlap[0], win.trim);
+    const int cy = axis_count(y + blk.origin[1], blk.global[1], win.patch[1], win.overlap[1], win.trim);
+    const int cx = axis_count(x + blk.origin[2], blk.global[2], win.patch[2], win.overlap[2], win.trim);
+    const int cnt = cz * cy * cx;
+    if (cnt > 1) {
+        const size_t i = ((size_t)z * blk.dims[1] + y) * blk.dims[2] + x;
+        const float wgt = (float)cnt;
+        for (int c = 0; c < channels; ++c) accum[c * avox + i] = __fdiv_rn(accum[c * avox + i], wgt);
     }
 }
 
@@ -340,10 +325,10 @@ extern "C" int exaspim_gather_patches(const void* vol_dev, int32_t vox_dtype,
     if (int rc = check_block(blk, "gather")) return rc;
     EXA_CHECK_ARG(vol_dev && starts_dev && out_dev && patch, "gather: NULL pointer");
     EXA_CHECK_ARG(n > 0 && patch[0] > 0 && patch[1] > 0 && patch[2] > 0, "gather: empty batch");
-    const size_t total = (size_t)patch[0] * patch[1] * patch[2] * n;
-    const unsigned grid = stream_grid(total);
+    EXA_CHECK_ARG((long long)n * patch[0] <= 65535 && patch[1] <= 65535, "gather: grid too large");
+    const dim3 grid((patch[2] + 127) / 128, patch[1], n * patch[0]);
     hipStream_t s = (hipStream_t)stream;
-#define GATHER(V) gather_kernel<V><<<grid, 256, 0, s>>>(vol_dev, *blk, starts_dev, n, patch[0], patch[1], patch[2], clip, has_clip, mn, denom, out_dev)
+#define GATHER(V) gather_kernel<V><<<grid, 128, 0, s>>>(vol_dev, *blk, starts_dev, patch[0], patch[1], patch[2], clip, has_clip, mn, denom, out_dev)
     switch (vox_dtype) {
         case EXASPIM_VOX_U8: GATHER(EXASPIM_VOX_U8); break;
         case EXASPIM_VOX_U16: GATHER(EXASPIM_VOX_U16); break;
@@ -366,15 +351,16 @@ extern "C" int exaspim_stitch_accumulate(const float* pred_dev, const int32_t* s
     if (int rc = check_window(win, "stitch")) return rc;
     EXA_CHECK_ARG(pred_dev && starts_dev && accum_dev, "stitch: NULL pointer");
     EXA_CHECK_ARG(n > 0 && channels >= 1 && channels <= 4, "stitch: n %d channels %d", n, channels);
-    const size_t total = (size_t)(win->patch[0] - 2 * win->trim) * (win->patch[1] - 2 * win->trim) *
-                         (win->patch[2] - 2 * win->trim) * n;
-    const unsigned grid = stream_grid(total);
+    const int oz = win->patch[0] - 2 * win->trim, oy = win->patch[1] - 2 * win->trim,
+              ox = win->patch[2] - 2 * win->trim;
+    EXA_CHECK_ARG((long long)n * oz <= 65535 && oy <= 65535, "stitch: grid too large");
+    const dim3 grid((ox + 127) / 128, oy, n * oz);
     hipStream_t s = (hipStream_t)stream;
     switch (channels) {
-        case 1: stitch_kernel<1><<<grid, 256, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
-        case 2: stitch_kernel<2><<<grid, 256, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
-        case 3: stitch_kernel<3><<<grid, 256, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
-        case 4: stitch_kernel<4><<<grid, 256, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
+        case 1: stitch_kernel<1><<<grid, 128, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
+        case 2: stitch_kernel<2><<<grid, 128, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
+        case 3: stitch_kernel<3><<<grid, 128, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
+        case 4: stitch_kernel<4><<<grid, 128, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
     }
     EXA_CHECK_HIP(hipGetLastError());
     return EXASPIM_OK;
@@ -386,8 +372,9 @@ extern "C" int exaspim_stitch_finalize(float* accum_dev, int32_t channels,
     if (int rc = check_block(blk, "finalize")) return rc;
     if (int rc = check_window(win, "finalize")) return rc;
     EXA_CHECK_ARG(accum_dev && channels >= 1, "finalize: bad arguments");
-    const size_t avox = (size_t)blk->dims[0] * blk->dims[1] * blk->dims[2];
-    finalize_kernel<<<stream_grid(avox), 256, 0, (hipStream_t)stream>>>(accum_dev, channels, *win, *blk);
+    EXA_CHECK_ARG(blk->dims[0] <= 65535 && blk->dims[1] <= 65535, "finalize: block too large");
+    const dim3 grid((blk->dims[2] + 255) / 256, blk->dims[1], blk->dims[0]);
+    finalize_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(accum_dev, channels, *win, *blk);
     EXA_CHECK_HIP(hipGetLastError());
     return EXASPIM_OK;
 }

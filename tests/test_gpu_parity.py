@@ -279,3 +279,62 @@ def test_synth_volume_matches_numpy(dev):
     _native.check(_native.lib().exaspim_synth_volume_u16(t.data_ptr(), blk, 5, None), "synth")
     want = synthetic.synth_volume(shape, seed=5, origin=origin, global_shape=gshape)
     np.testing.assert_array_equal(t.cpu().numpy().view(np.uint16), want)
+
+
+# ------------------------------------------------ full-size (BASELINE configs[1]) ---
+def _periodic_volume(edge, seed=17):
+    """Volume whose 64^3 cells are identical: with stride 64 every patch that is
+    not reflect-padded sees the same input, so the stitched output is periodic."""
+    cell = synthetic.synth_volume((64, 64, 64), seed=seed)
+    cell[cell < 60] = 0  # 3 % exact zeros: the 1st percentile is 0 for every crop
+    reps = -(-edge // 64)
+    return np.tile(cell, (reps, reps, reps))[:edge, :edge, :edge].copy()
+
+
+def test_full_size_512_periodic_property_and_oracle(dev, oracle):
+    """512^3 (BASELINE configs[1]) through a size-independent property: a
+    64-periodic input gives a 64-periodic output away from the borders, and that
+    output equals the CPU oracle's on a 224^3 crop of the same periodic input."""
+    from aind_exaspim_neuron_segmentation_amd import inference
+
+    model, sd = make_model(dev)
+    big = _periodic_volume(512)
+    small = _periodic_volume(224)
+    # same percentile pair on both sizes (the value distribution is the same)
+    assert tuple(np.percentile(np.minimum(big, 1000), (1, 99.9))) == tuple(
+        np.percentile(np.minimum(small, 1000), (1, 99.9))
+    )
+    got = inference.predict(big, model, batch_size=8, verbose=False)
+    assert got.shape == (3, 512, 512, 512)
+    # 1. periodicity of the region covered only by unpadded patches: [72, 456)
+    a = got[:, 72:392, 72:392, 72:392]
+    assert np.abs(a[:, :256] - a[:, 64:320]).max() < 1e-6
+    assert np.abs(a[:, :, :256] - a[:, :, 64:320]).max() < 1e-6
+    assert np.abs(a[:, :, :, :256] - a[:, :, :, 64:320]).max() < 1e-6
+    # 2. borders: first 8 voxels are never covered; 512 = 448 + 64 is covered to the end
+    assert not got[:, :8].any() and not got[:, :, :8].any() and not got[:, :, :, :8].any()
+    assert got[:, 511, 100, 100].all()
+    # 3. against the oracle on the 224^3 crop (27 patches), mapped through the period
+    want = oracle.predict(small, oracle.OracleModel(sd), batch_size=9)
+    idx = np.arange(8, 456)
+    src = np.where(idx < 136, idx, 72 + (idx - 72) % 64)
+    sub = np.ix_(np.arange(3), idx[::7], idx[::5], idx)
+    ref = np.ix_(np.arange(3), src[::7], src[::5], src)
+    err = np.abs(got[sub] - want[ref]).max()
+    print(f"512^3 periodic vs oracle(224^3): max|diff| = {err:.3e}")
+    assert err < 1e-5
+
+
+def test_half_width_model_channel_padding(dev, oracle):
+    """width_multiplier = 0.5 (16..256 channels): every level is padded to 32
+    channels inside the engine; results must not change."""
+    from aind_exaspim_neuron_segmentation_amd.machine_learning.unet3d import UNet3D
+
+    sd = synthetic.synth_state_dict(3, 0.5, seed=6)
+    model = UNet3D(output_channels=3, width_multiplier=0.5)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    model.to(dev).eval()
+    x = normalized_input(oracle, (32, 32, 48), seed=50, n=2)
+    want = oracle.unet_forward(x, oracle.OracleModel(sd).sd).numpy()
+    got = model(x.to(dev)).cpu().numpy()
+    assert np.abs(got - want).max() < 1e-4
