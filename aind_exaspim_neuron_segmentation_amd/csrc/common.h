@@ -88,12 +88,12 @@ struct ConvArgs {
     int cout;            // padded
     int n, d, h, w;      // batch of patches and their spatial size at this level
     float slope;
-    int debug = 0;       // ablation switches (EXASPIM_CONV_DEBUG), 0 in production
 };
 
 int launch_conv3x3x3(int dtype, const ConvArgs& a, hipStream_t stream);
 
-int launch_conv_first(int dtype, const float* x, const float* w, const float* bias,
+// xpad: scratch for the zero-bordered copy of x, n * (d+2)(h+2)(wd+2) floats
+int launch_conv_first(int dtype, const float* x, float* xpad, const float* w, const float* bias,
                       void* dst, int n, int d, int h, int wd, int c0p, float slope,
                       hipStream_t stream);
 int launch_maxpool2(int dtype, const void* src, void* dst, int n, int d, int h, int w,

@@ -17,6 +17,7 @@ constexpr float kLeakySlope = 0.01f;  // unet3d.py:145,148
 
 struct Workspace {
     size_t skip[5], a[5], b[5];
+    size_t xpad;  // zero-bordered float32 copy of the input patches (inc.0)
     size_t bytes;
 };
 
@@ -70,6 +71,8 @@ static Workspace make_workspace(const UNetPlan& p, int n, int d, int h, int w) {
         ws.a[l] = off; off += sz;
         ws.b[l] = off; off += sz;
     }
+    ws.xpad = off;
+    off += align_up((size_t)n * (d + 2) * (h + 2) * (w + 2) * sizeof(float), 256);
     ws.bytes = off;
     return ws;
 }
@@ -118,7 +121,8 @@ static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, in
 #define RUN(expr) do { rc = (expr); if (rc) return rc; } while (0)
 
     // encoder (unet3d.py:93-97)
-    RUN(launch_conv_first(dt, x, reinterpret_cast<const float*>(e->packed + p.first_w_off),
+    RUN(launch_conv_first(dt, x, reinterpret_cast<float*>(base + ws.xpad),
+                          reinterpret_cast<const float*>(e->packed + p.first_w_off),
                           reinterpret_cast<const float*>(e->packed + p.first_b_off), A(0), n, d,
                           h, w, p.c0p, kLeakySlope, stream));
     RUN(conv(0, A(0), nullptr, skip(0), 0));                      // x1

@@ -70,14 +70,29 @@ struct F16T {
 // Cin = 1, so the contraction is only over the 27 taps: per 32 voxels x 32
 // output channels it is a 32 x 28 x 32 GEMM (27 taps + one zero column), run as
 // 14 exact-fp32 v_mfma_f32_32x32x2_f32. A = weights W[cout][tap] (14 floats per
-// lane, loaded once per wave), B = X[tap][voxel] gathered straight from the
-// float32 patch (zero outside the patch = the conv padding). The patch is read
-// in fp32 whatever the network's storage type, so inc.0 adds no input rounding.
+// lane, loaded once per wave), B = X[tap][voxel] gathered straight from a copy
+// of the float32 patch with a one-voxel zero border (pad_input_kernel), so a tap
+// is one add and one load with no bounds arithmetic. The patch is read in fp32
+// whatever the network's storage type: inc.0 adds no input rounding.
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+// (n, d, h, w) float32 -> (n, d+2, h+2, w+2) with a zero border.
+__global__ __launch_bounds__(128) void pad_input_kernel(const float* __restrict__ x,
+                                                        float* __restrict__ xp, int d, int h, int w) {
+    const int px = blockIdx.x * blockDim.x + threadIdx.x;
+    if (px >= w + 2) return;
+    const int py = blockIdx.y;
+    const int nb = blockIdx.z / (d + 2), pz = blockIdx.z - nb * (d + 2);
+    const int z = pz - 1, y = py - 1, xx = px - 1;
+    float v = 0.f;
+    if ((unsigned)z < (unsigned)d && (unsigned)y < (unsigned)h && (unsigned)xx < (unsigned)w)
+        v = x[(((size_t)nb * d + z) * h + y) * w + xx];
+    xp[(((size_t)nb * (d + 2) + pz) * (h + 2) + py) * (w + 2) + px] = v;
+}
 
 template <typename T, int MT>
 __global__ __launch_bounds__(256) void conv_first_kernel(
-    const float* __restrict__ x, const float* __restrict__ w,
+    const float* __restrict__ xp, const float* __restrict__ w,
     const float* __restrict__ bias, void* __restrict__ dst, int nvox, int d, int h, int wd,
     int c0p, float slope) {
     const int lane = threadIdx.x & 63;
@@ -85,19 +100,18 @@ __global__ __launch_bounds__(256) void conv_first_kernel(
     const int half = lane >> 5, r = lane & 31;
     const int co_tile = blockIdx.y * 32;
     const int hw = h * wd, dhw = d * hw;
+    const int pw = wd + 2, phw = (h + 2) * pw;   // padded row / plane strides
 
-    // this lane's 14 taps (k = 2 * ks + half): weight and relative input offset
+    // this lane's 14 taps (k = 2 * ks + half): weight and offset in the padded patch
     float wk[14];
-    int rel[14], dzyx[14];
+    int rel[14];
 #pragma unroll
     for (int ks = 0; ks < 14; ++ks) {
         const int t = 2 * ks + half;
         const bool real = t < 27;
         const int tt = real ? t : 0;
-        const int dz = tt / 9 - 1, dy = (tt / 3) % 3 - 1, dx = tt % 3 - 1;
-        wk[ks] = real ? w[tt * c0p + co_tile + r] : 0.f;
-        rel[ks] = dz * hw + dy * wd + dx;
-        dzyx[ks] = real ? ((dz + 1) | ((dy + 1) << 2) | ((dx + 1) << 4)) : 0x40;
+        wk[ks] = real ? w[tt * c0p + co_tile + r] : 0.f;   // zero weight for the 28th column
+        rel[ks] = (tt / 9) * phw + ((tt / 3) % 3) * pw + tt % 3;
     }
 
     const int v0 = (blockIdx.x * 4 + wave) * (MT * 32);
@@ -107,16 +121,12 @@ __global__ __launch_bounds__(256) void conv_first_kernel(
     for (int mt = 0; mt < MT; ++mt) {
         const int v = v0 + mt * 32 + r;
         const int vc = v < nvox ? v : nvox - 1;
-        const int sp = vc % dhw;
-        const int zz = sp / hw, yy = (sp / wd) % h, xx = sp % wd;
+        const int nb = vc / dhw, sp = vc - nb * dhw;
+        const int zz = sp / hw, yy = (sp - zz * hw) / wd, xx = sp - zz * hw - yy * wd;
+        // padded address of tap (0,0,0) = voxel (zz-1, yy-1, xx-1)
+        const float* base = xp + ((size_t)nb * (d + 2) + zz) * phw + yy * pw + xx;
 #pragma unroll
-        for (int ks = 0; ks < 14; ++ks) {
-            const int c = dzyx[ks];
-            const int z = zz + (c & 3) - 1, y = yy + ((c >> 2) & 3) - 1, xq = xx + ((c >> 4) & 3) - 1;
-            const bool ok = c < 0x40 && (unsigned)z < (unsigned)d && (unsigned)y < (unsigned)h &&
-                            (unsigned)xq < (unsigned)wd;
-            xv[mt][ks] = ok ? x[vc + rel[ks]] : 0.f;
-        }
+        for (int ks = 0; ks < 14; ++ks) xv[mt][ks] = base[rel[ks]];
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
     }
@@ -131,9 +141,10 @@ __global__ __launch_bounds__(256) void conv_first_kernel(
     constexpr int G = T::kG;
     constexpr int ES = 16 / G;
     constexpr int RECB = 32 * ES;           // bytes of one voxel's 32-channel slice
+    constexpr int RECP = RECB + 16;         // padded LDS stride (2-way instead of 8-way conflicts)
     constexpr int PPV = RECB / 16;
-    __shared__ __attribute__((aligned(16))) char tr[4 * 32 * RECB];
-    char* wl = tr + wave * (32 * RECB);
+    __shared__ __attribute__((aligned(16))) char tr[4 * 32 * RECP];
+    char* wl = tr + wave * (32 * RECP);
     float4 bq[4];  // bias before the stores (vmcnt counts stores on gfx950)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -148,7 +159,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(
                           acc[mt][4 * q + 2] + b.z, acc[mt][4 * q + 3] + b.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = o[j] > 0.f ? o[j] : o[j] * slope;
-            char* slot = wl + r * RECB + cl * ES;
+            char* slot = wl + r * RECP + cl * ES;
             if (G == 4) {
                 *reinterpret_cast<float4*>(slot) = make_float4(o[0], o[1], o[2], o[3]);
             } else {
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(
         for (int k = 0; k < 32 * PPV / 64; ++k) {
             const int p = k * 64 + lane;
             const int v = v0 + mt * 32 + p / PPV;
-            const uint4 val = *reinterpret_cast<const uint4*>(wl + p * 16);
+            const uint4 val = *reinterpret_cast<const uint4*>(wl + (p / PPV) * RECP + (p % PPV) * 16);
             if (v < nvox)
                 *reinterpret_cast<uint4*>(static_cast<char*>(dst) +
                                           ((size_t)v * c0p + co_tile) * ES + (p % PPV) * 16) = val;
@@ -304,15 +315,19 @@ static inline unsigned stream_grid(size_t items) {
         default: set_error("unknown dtype %d", dtype); return EXASPIM_E_INVALID; \
     }
 
-int launch_conv_first(int dtype, const float* x, const float* w, const float* bias,
+int launch_conv_first(int dtype, const float* x, float* xpad, const float* w, const float* bias,
                       void* dst, int n, int d, int h, int wd, int c0p, float slope,
                       hipStream_t stream) {
     const size_t nvox = (size_t)n * d * h * wd;
     constexpr int MT = 4;
     const size_t blocks = (nvox + 4 * MT * 32 - 1) / (4 * MT * 32);
     EXA_CHECK_ARG(nvox > 0 && nvox < 0x7fffffffULL && c0p % 32 == 0, "conv_first: bad size");
+    EXA_CHECK_ARG((long long)n * (d + 2) <= 65535 && h + 2 <= 65535, "conv_first: grid too large");
+    const dim3 pgrid((wd + 2 + 127) / 128, h + 2, n * (d + 2));
+    pad_input_kernel<<<pgrid, 128, 0, stream>>>(x, xpad, d, h, wd);
+    EXA_CHECK_HIP(hipGetLastError());
     dim3 grid((unsigned)blocks, c0p / 32);
-    DISPATCH_T(dtype, (conv_first_kernel<T, MT><<<grid, 256, 0, stream>>>(x, w, bias, dst, (int)nvox, d, h, wd, c0p, slope)));
+    DISPATCH_T(dtype, (conv_first_kernel<T, MT><<<grid, 256, 0, stream>>>(xpad, w, bias, dst, (int)nvox, d, h, wd, c0p, slope)));
     EXA_CHECK_HIP(hipGetLastError());
     return EXASPIM_OK;
 }
