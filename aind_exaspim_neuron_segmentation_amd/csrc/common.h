@@ -88,9 +88,18 @@ struct ConvArgs {
     int cout;            // padded
     int n, d, h, w;      // batch of patches and their spatial size at this level
     float slope;
+    // Optional fused OutConv (unet3d.py:318) + sigmoid (inference.py:158): when
+    // head_out is set (32-cout layers only) the conv's activations are not stored;
+    // the 1x1x1 head runs on the accumulators and writes NCDHW float32.
+    const float* head_w = nullptr;  // float[head_oc][32]
+    const float* head_b = nullptr;  // float[head_oc]
+    float* head_out = nullptr;      // float (n, head_oc, d, h, w)
+    int head_oc = 0;
+    int head_sigmoid = 0;
 };
 
 int launch_conv3x3x3(int dtype, const ConvArgs& a, hipStream_t stream);
+bool conv_can_fuse_head(int cout, int w, int head_oc);
 
 // xpad: scratch for the zero-bordered copy of x, n * (d+2)(h+2)(wd+2) floats
 int launch_conv_first(int dtype, const float* x, float* xpad, const float* w, const float* bias,

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
 // global -> VGPR with the halo, one copy per workgroup instead of one L2 read per
 // wave): with 4 x 32-voxel tiles per wave the per-wave weight stream would
 // otherwise be 3x the activation traffic.
-template <typename Tag, int TZ, int TY, int TX, int WAVES_M, int WAVES_N, int YXW, int NT, int MINW, int PDG, bool WLDS, bool PADX = true>
+template <typename Tag, int TZ, int TY, int TX, int WAVES_M, int WAVES_N, int YXW, int NT, int MINW, int PDG, bool WLDS, bool PADX = true, int HEAD = 0>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_zcol(
     ConvArgs a, int tiles_z, int tiles_y, int tiles_x) {
     constexpr int G = Tag::kG;
@@ -521,6 +521,59 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_zcol(
         }
     }
 
+    if (HEAD > 0) {
+        // ---- fused head: OutConv 1x1x1 (+ sigmoid) on the accumulators -----------
+        // lane (voxel r, half h) holds channels 8q + 4h + j of its voxel: a 16-term
+        // partial dot product per output, completed by the other half-wave.
+        static_assert(HEAD == 0 || NT == 1, "the fused head needs the whole 32-channel record");
+        float hw[HEAD > 0 ? HEAD : 1][16];
+        float4 bq4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bq4[q] = *reinterpret_cast<const float4*>(a.bias + 8 * q + 4 * half);
+#pragma unroll
+            for (int o = 0; o < HEAD; ++o) {
+                const float4 t = *reinterpret_cast<const float4*>(a.head_w + o * 32 + 8 * q + 4 * half);
+                hw[o][4 * q + 0] = t.x; hw[o][4 * q + 1] = t.y;
+                hw[o][4 * q + 2] = t.z; hw[o][4 * q + 3] = t.w;
+            }
+        }
+        float hb[HEAD > 0 ? HEAD : 1];
+#pragma unroll
+        for (int o = 0; o < HEAD; ++o) hb[o] = a.head_b[o];
+        const size_t plane = (size_t)a.h * a.w;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int j = mt / TZ, z = mt % TZ;
+            float part[HEAD > 0 ? HEAD : 1];
+#pragma unroll
+            for (int o = 0; o < HEAD; ++o) part[o] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float bb[4] = {bq4[q].x, bq4[q].y, bq4[q].z, bq4[q].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float v = acc[mt][0][4 * q + k] + bb[k];
+                    v = v > 0.f ? v : v * a.slope;
+#pragma unroll
+                    for (int o = 0; o < HEAD; ++o) part[o] = fmaf(v, hw[o][4 * q + k], part[o]);
+                }
+            }
+            const int pos = (wm * YXW + j) * 32 + r;
+            const int gz = z0 + z, gy = y0 + pos / TX, gx = x0 + pos % TX;
+            const bool ok = gz < a.d && gy < a.h && gx < a.w;
+#pragma unroll
+            for (int o = 0; o < HEAD; ++o) {
+                float t = part[o] + __shfl_xor(part[o], 32) + hb[o];
+                if (a.head_sigmoid) t = 1.f / (1.f + expf(-t));
+                // outputs are dealt to the two half-waves so both store
+                if (ok && (o & 1) == half)
+                    a.head_out[(((size_t)nb * HEAD + o) * a.d + gz) * plane + (size_t)gy * a.w + gx] = t;
+            }
+        }
+        return;
+    }
+
     // ---- epilogue: bias + LeakyReLU, transposed through LDS ------------------
     char* wl = reinterpret_cast<char*>(lds) + wave * (32 * RECP);
     float4 bq[NT][4];  // bias before the stores (vmcnt counts stores on gfx950)
@@ -571,7 +624,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_zcol(
     }
 }
 
-template <typename Tag, int TZ, int TY, int TX, int WAVES_M, int WAVES_N, int YXW, int NT, int MINW, int PDG, bool WLDS = false, bool PADX = true>
+template <typename Tag, int TZ, int TY, int TX, int WAVES_M, int WAVES_N, int YXW, int NT, int MINW, int PDG, bool WLDS = false, bool PADX = true, int HEAD = 0>
 static int launch_zcol(const ConvArgs& a, hipStream_t stream) {
     constexpr int NWG = WAVES_N * NT * 32;
     if (a.cout % NWG != 0) {
@@ -585,7 +638,7 @@ static int launch_zcol(const ConvArgs& a, hipStream_t stream) {
         return EXASPIM_E_INVALID;
     }
     dim3 grid((unsigned)blocks, a.cout / NWG);
-    conv3x3x3_zcol<Tag, TZ, TY, TX, WAVES_M, WAVES_N, YXW, NT, MINW, PDG, WLDS, PADX>
+    conv3x3x3_zcol<Tag, TZ, TY, TX, WAVES_M, WAVES_N, YXW, NT, MINW, PDG, WLDS, PADX, HEAD>
         <<<grid, WAVES_M * WAVES_N * 64, 0, stream>>>(a, tz, ty, tx);
     EXA_CHECK_HIP(hipGetLastError());
     return EXASPIM_OK;
@@ -620,8 +673,17 @@ static int launch_typed(const ConvArgs& a, hipStream_t stream) {
     // a 96^3 patch; any other size runs on the closest shape with masking.
     if (a.w >= 16 && a.w % 16 == 0) {
         // 32-cout slices: z-column tiles with the chunk's weights shared through LDS
-        if (a.cout % 64 != 0)
+        if (a.cout % 64 != 0) {
+            if (a.head_out && a.cout == 32) {
+                switch (a.head_oc) {
+                    case 1: return launch_zcol<Tag, 4, 8, 16, 4, 1, 1, 1, 2, 1, true, false, 1>(a, stream);
+                    case 2: return launch_zcol<Tag, 4, 8, 16, 4, 1, 1, 1, 2, 1, true, false, 2>(a, stream);
+                    case 3: return launch_zcol<Tag, 4, 8, 16, 4, 1, 1, 1, 2, 1, true, false, 3>(a, stream);
+                    case 4: return launch_zcol<Tag, 4, 8, 16, 4, 1, 1, 1, 2, 1, true, false, 4>(a, stream);
+                }
+            }
             return launch_zcol<Tag, 4, 8, 16, 4, 1, 1, 1, 2, 1, true, false>(a, stream);
+        }
         return launch_cfg<Tag, 4, 8, 16, 4, 1, 4, 2, 2>(a, stream);
     }
     if (a.w > 12) {
@@ -637,11 +699,17 @@ static int launch_typed(const ConvArgs& a, hipStream_t stream) {
     return launch_cfg<Tag, 6, 6, 6, 2, 1, 4, 1, 2>(a, stream);
 }
 
+bool conv_can_fuse_head(int cout, int w, int head_oc) {
+    return cout == 32 && w >= 16 && w % 16 == 0 && head_oc >= 1 && head_oc <= 4;
+}
+
 int launch_conv3x3x3(int dtype, const ConvArgs& a, hipStream_t stream) {
     const int kc = dtype == EXASPIM_DT_F32 ? 8 : 16;
     EXA_CHECK_ARG(a.ca % kc == 0 && a.cb % kc == 0 && a.cout % 32 == 0 && a.ca > 0,
                   "conv: channels (%d,%d)->%d not padded", a.ca, a.cb, a.cout);
     EXA_CHECK_ARG(a.n > 0 && a.d > 0 && a.h > 0 && a.w > 0, "conv: empty input");
+    EXA_CHECK_ARG(!a.head_out || conv_can_fuse_head(a.cout, a.w, a.head_oc),
+                  "conv: fused head needs cout 32, w %% 16 == 0, 1..4 outputs");
     {   // the LDS-DMA staging addresses one patch of one source with 32-bit offsets
         const unsigned long long rec = (unsigned long long)a.d * a.h * a.w *
                                        (a.ca > a.cb ? a.ca : a.cb) * (dtype == EXASPIM_DT_F32 ? 4 : 2);

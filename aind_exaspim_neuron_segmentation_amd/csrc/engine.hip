@@ -93,9 +93,18 @@ static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, in
     const int dt = p.dtype;
     int rc;
 
+    // the last conv (up4.3) can run the 1x1x1 head on its accumulators
+    const bool fuse_head = conv_can_fuse_head(p.conv[kNumMfmaConvs - 1].cout, w, p.out_channels);
     auto conv = [&](int idx, const void* sa, const void* sb, void* dst, int l) -> int {
         const ConvLayer& L = p.conv[idx];
         ConvArgs a;
+        if (idx == kNumMfmaConvs - 1 && fuse_head) {
+            a.head_w = reinterpret_cast<const float*>(e->packed + p.head_w_off);
+            a.head_b = reinterpret_cast<const float*>(e->packed + p.head_b_off);
+            a.head_out = out;
+            a.head_oc = p.out_channels;
+            a.head_sigmoid = apply_sigmoid;
+        }
         a.src_a = sa; a.src_b = sb; a.ca = L.ca; a.cb = L.cb;
         a.weights = e->packed + L.w_off;
         a.bias = reinterpret_cast<const float*>(e->packed + L.b_off);
@@ -145,6 +154,7 @@ static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, in
         RUN(conv(i0 + 1, B(l), nullptr, A(l), l));
         prev = A(l);
     }
+    if (!fuse_head)
     RUN(launch_head(dt, prev, reinterpret_cast<const float*>(e->packed + p.head_w_off),
                     reinterpret_cast<const float*>(e->packed + p.head_b_off), out, n, d, h, w,
                     p.c0p, p.out_channels, apply_sigmoid, stream));

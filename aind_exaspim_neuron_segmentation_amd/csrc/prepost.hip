@@ -172,33 +172,78 @@ __global__ __launch_bounds__(128) void stitch_kernel(const float* __restrict__ p
                                                      exaspim_window win,
                                                      float* __restrict__ accum,
                                                      exaspim_block blk) {
-    const int oz = win.patch[0] - 2 * win.trim, ox = win.patch[2] - 2 * win.trim;
+    const int oz = win.patch[0] - 2 * win.trim, oy = win.patch[1] - 2 * win.trim,
+              ox = win.patch[2] - 2 * win.trim;
     const size_t pvox = (size_t)win.patch[0] * win.patch[1] * win.patch[2];
     const size_t avox = (size_t)blk.dims[0] * blk.dims[1] * blk.dims[2];
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= ox) return;
     const int y = blockIdx.y;
     const int p = blockIdx.z / oz, z = blockIdx.z - p * oz;
     const int* sp = starts + 3 * p;
+
+    // Patches of the batch whose trimmed box meets patch p's (one ballot per
+    // block): the per-voxel coverage tests below then run for the 1-7 neighbours
+    // instead of for the whole batch. Batches of more than 64 test everything.
+    __shared__ unsigned long long near_mask;
+    const bool wide = n > 64;
+    if (!wide) {
+        if (threadIdx.x < 64) {
+            const int j = threadIdx.x;
+            bool hit = false;
+            if (j < n) {
+                const int* sj = starts + 3 * j;
+                const int dz = sj[0] - sp[0], dy = sj[1] - sp[1], dx = sj[2] - sp[2];
+                hit = dz > -oz && dz < oz && dy > -oy && dy < oy && dx > -ox && dx < ox;
+            }
+            const unsigned long long m = __ballot(hit);
+            if (threadIdx.x == 0) near_mask = m;
+        }
+        __syncthreads();
+    }
+    if (x >= ox) return;
     const int gz = sp[0] + win.trim + z, gy = sp[1] + win.trim + y, gx = sp[2] + win.trim + x;
     if (gz >= blk.global[0] || gy >= blk.global[1] || gx >= blk.global[2]) return;
     const int lz = gz - blk.origin[0], ly = gy - blk.origin[1], lx = gx - blk.origin[2];
     if ((unsigned)lz >= (unsigned)blk.dims[0] || (unsigned)ly >= (unsigned)blk.dims[1] ||
         (unsigned)lx >= (unsigned)blk.dims[2])
         return;
-    // The first patch of the batch that covers this voxel owns it and adds
-    // every covering patch in batch order (= the reference's loop order).
-    for (int j = 0; j < p; ++j)
-        if (covered(starts + 3 * j, win, blk.global, gz, gy, gx)) return;
     const size_t a = ((size_t)lz * blk.dims[1] + ly) * blk.dims[2] + lx;
+    // The first patch of the batch that covers this voxel owns it and adds every
+    // covering patch in batch order (= the reference's loop order).
+    if (wide) {
+        for (int j = 0; j < p; ++j)
+            if (covered(starts + 3 * j, win, blk.global, gz, gy, gx)) return;
+        float s[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) s[c] = accum[c * avox + a];
+        for (int j = p; j < n; ++j) {
+            const int* sj = starts + 3 * j;
+            if (j != p && !covered(sj, win, blk.global, gz, gy, gx)) continue;
+            const size_t o = ((size_t)(gz - sj[0]) * win.patch[1] + (gy - sj[1])) * win.patch[2] + (gx - sj[2]);
+#pragma unroll
+            for (int c = 0; c < C; ++c) s[c] += pred[((size_t)j * C + c) * pvox + o];
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) accum[c * avox + a] = s[c];
+        return;
+    }
+    const unsigned long long near = near_mask;
+    unsigned long long before = near & ((1ULL << p) - 1ULL);
+    while (before) {
+        const int j = __ffsll((long long)before) - 1;
+        before &= before - 1ULL;
+        if (covered(starts + 3 * j, win, blk.global, gz, gy, gx)) return;
+    }
     float s[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) s[c] = accum[c * avox + a];
-    for (int j = p; j < n; ++j) {
+    unsigned long long rest = near & ~((1ULL << p) - 1ULL);  // p itself and later neighbours
+    while (rest) {
+        const int j = __ffsll((long long)rest) - 1;
+        rest &= rest - 1ULL;
         const int* sj = starts + 3 * j;
         if (j != p && !covered(sj, win, blk.global, gz, gy, gx)) continue;
-        const int pz = gz - sj[0], py = gy - sj[1], px = gx - sj[2];
-        const size_t o = ((size_t)pz * win.patch[1] + py) * win.patch[2] + px;
+        const size_t o = ((size_t)(gz - sj[0]) * win.patch[1] + (gy - sj[1])) * win.patch[2] + (gx - sj[2]);
 #pragma unroll
         for (int c = 0; c < C; ++c) s[c] += pred[((size_t)j * C + c) * pvox + o];
     }

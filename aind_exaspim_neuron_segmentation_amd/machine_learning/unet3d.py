@@ -175,17 +175,22 @@ class UNet3D(nn.Module):
         self._engine = handle
         self._engine_key = key
 
-    def _get_workspace(self, n, d, h, w, device):
+    def _get_workspace(self, n, d, h, w, device, stream):
+        """Scratch buffer for one forward; one per HIP stream so that batches in
+        flight on different streams never share activations."""
         need = _native.lib().exaspim_unet_workspace_bytes(self._engine, n, d, h, w)
         if need == 0:
             raise RuntimeError(
                 "Sizes of tensors must match: " + _native.last_error()
             )
-        ws = self._workspace
-        if ws is None or ws.numel() < need or ws.device != device:
-            self._workspace = None
+        if self._workspace is None:
+            self._workspace = {}
+        key = (str(device), stream)
+        ws = self._workspace.get(key)
+        if ws is None or ws.numel() < need:
+            self._workspace.pop(key, None)
             ws = torch.empty(need, dtype=torch.uint8, device=device)
-            self._workspace = ws
+            self._workspace[key] = ws
         return ws
 
     # ---- forward -----------------------------------------------------------
@@ -227,12 +232,12 @@ class UNet3D(nn.Module):
         device = x.device
         with torch.cuda.device(device):
             self._ensure_engine(device)
-            ws = self._get_workspace(n, d, h, w, device)
+            stream = torch.cuda.current_stream(device).cuda_stream
+            ws = self._get_workspace(n, d, h, w, device, stream)
             if out is None:
                 out = torch.empty(
                     (n, self.output_channels, d, h, w), dtype=torch.float32, device=device
                 )
-            stream = torch.cuda.current_stream(device).cuda_stream
             _native.check(
                 _native.lib().exaspim_unet_forward(
                     self._engine, x.data_ptr(), out.data_ptr(), n, d, h, w,
