@@ -667,6 +667,20 @@ static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
     return EXASPIM_OK;
 }
 
+// 32-cout slice on z-column tiles of TZ planes, with or without the fused head
+template <typename Tag, int TZ>
+static int launch_zcol_head(const ConvArgs& a, hipStream_t stream) {
+    if (a.head_out && a.cout == 32) {
+        switch (a.head_oc) {
+            case 1: return launch_zcol<Tag, TZ, 8, 16, 4, 1, 1, 1, 2, 1, true, false, 1>(a, stream);
+            case 2: return launch_zcol<Tag, TZ, 8, 16, 4, 1, 1, 1, 2, 1, true, false, 2>(a, stream);
+            case 3: return launch_zcol<Tag, TZ, 8, 16, 4, 1, 1, 1, 2, 1, true, false, 3>(a, stream);
+            case 4: return launch_zcol<Tag, TZ, 8, 16, 4, 1, 1, 1, 2, 1, true, false, 4>(a, stream);
+        }
+    }
+    return launch_zcol<Tag, TZ, 8, 16, 4, 1, 1, 1, 2, 1, true, false>(a, stream);
+}
+
 template <typename Tag>
 static int launch_typed(const ConvArgs& a, hipStream_t stream) {
     // Widest x extent first: the tile shapes follow the 96/48/24/12/6 pyramid of
@@ -674,15 +688,9 @@ static int launch_typed(const ConvArgs& a, hipStream_t stream) {
     if (a.w >= 16 && a.w % 16 == 0) {
         // 32-cout slices: z-column tiles with the chunk's weights shared through LDS
         if (a.cout % 64 != 0) {
-            if (a.head_out && a.cout == 32) {
-                switch (a.head_oc) {
-                    case 1: return launch_zcol<Tag, 4, 8, 16, 4, 1, 1, 1, 2, 1, true, false, 1>(a, stream);
-                    case 2: return launch_zcol<Tag, 4, 8, 16, 4, 1, 1, 1, 2, 1, true, false, 2>(a, stream);
-                    case 3: return launch_zcol<Tag, 4, 8, 16, 4, 1, 1, 1, 2, 1, true, false, 3>(a, stream);
-                    case 4: return launch_zcol<Tag, 4, 8, 16, 4, 1, 1, 1, 2, 1, true, false, 4>(a, stream);
-                }
-            }
-            return launch_zcol<Tag, 4, 8, 16, 4, 1, 1, 1, 2, 1, true, false>(a, stream);
+            // 6-plane tiles when the depth divides (96, 48, 24): more dz reuse per LDS read
+            if (a.d % 6 == 0) return launch_zcol_head<Tag, 6>(a, stream);
+            return launch_zcol_head<Tag, 4>(a, stream);
         }
         return launch_cfg<Tag, 4, 8, 16, 4, 1, 4, 2, 2>(a, stream);
     }

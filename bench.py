@@ -198,7 +198,7 @@ def main():
             with open(tpath) as f:
                 kernels = json.load(f).get("kernels", {})
             tag = {"bf16": "BF16Tag", "fp16": "F16Tag", "fp32": "F32Tag"}[args.dtype]
-            entry = kernels.get(f"conv3x3x3_zcol<{tag}, 4, 8, 16, 4, 1, 1, 1, 2, 1, true, false>")
+            entry = kernels.get(f"conv3x3x3_zcol<{tag}, 6, 8, 16, 4, 1, 1, 1, 2, 1, true, false, 0>")
             if entry:
                 traffic = entry["hbm_bytes_per_launch"]
         result = {
@@ -227,7 +227,7 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "conv3x3x3_zcol<4x8x16 tile, 32 couts> (the 96^3-level convs inc.3, up4.0, up4.3)",
+                "kernel": "conv3x3x3_zcol<6x8x16 tile, 32 couts> (the 96^3-level convs inc.3, up4.0, up4.3+head)",
                 "algorithmic_flop_per_launch": flops / launches if launches else None,
                 "achieved": achieved,
                 "peak": peak,
