@@ -139,7 +139,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
     const int wm = wave / WAVES_N;
     const int wn = wave % WAVES_N;
     const int half = lane >> 5;
-    const int r = lane & 31;
+    // 16-wide rows: second row of a 32-voxel group in rotated x order, x = (i - HX)
+    // mod 16, so its lanes use the bank slots the first row leaves free (see zcol)
+    const int r = (TX == 16 && (lane & 16)) ? 16 + (((lane & 15) - HX) & 15) : (lane & 31);
 
     int bid;
     {
@@ -178,13 +180,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
         vidx[it] = ok ? (gz * a.h + gy) * a.w + gx : -1;
     }
 
+    // accumulators start from the folded bias: register 4q+k of a lane is channel
+    // 8q + 4*half + k of its slice (no bias pass in the epilogue)
     f32x16 acc[MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int q = 0; q < 4; ++q) {
+            const float4 b = *reinterpret_cast<const float4*>(a.bias + (ntile0 + nt) * 32 + 8 * q + 4 * half);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+            for (int mt = 0; mt < MT; ++mt) {
+                acc[mt][nt][4 * q + 0] = b.x; acc[mt][nt][4 * q + 1] = b.y;
+                acc[mt][nt][4 * q + 2] = b.z; acc[mt][nt][4 * q + 3] = b.w;
+            }
+        }
 
     const int nchunks = (a.ca + a.cb) / KC;
     uint4 stg[NITEMS];
@@ -265,14 +274,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
 
     // ---- epilogue: bias + LeakyReLU, transposed through LDS ------------------
     char* wl = reinterpret_cast<char*>(lds) + wave * (32 * RECP);
-    // bias first: a load inside the store loop would wait (vmcnt counts stores on
-    // gfx950) for every store issued before it
-    float4 bq[NT][4];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            bq[nt][q] = *reinterpret_cast<const float4*>(a.bias + ntile0 * 32 + nt * 32 + 8 * q + 4 * half);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -280,15 +281,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int cl = nt * 32 + 8 * q + 4 * half;  // channel inside the slice
-                const float4 b = bq[nt][q];
-                float v0 = acc[mt][nt][4 * q + 0] + b.x;
-                float v1 = acc[mt][nt][4 * q + 1] + b.y;
-                float v2 = acc[mt][nt][4 * q + 2] + b.z;
-                float v3 = acc[mt][nt][4 * q + 3] + b.w;
-                v0 = v0 > 0.f ? v0 : v0 * a.slope;
-                v1 = v1 > 0.f ? v1 : v1 * a.slope;
-                v2 = v2 > 0.f ? v2 : v2 * a.slope;
-                v3 = v3 > 0.f ? v3 : v3 * a.slope;
+                // LeakyReLU with 0 <= slope <= 1 is max(v, slope * v)
+                float v0 = acc[mt][nt][4 * q + 0], v1 = acc[mt][nt][4 * q + 1];
+                float v2 = acc[mt][nt][4 * q + 2], v3 = acc[mt][nt][4 * q + 3];
+                v0 = fmaxf(v0, v0 * a.slope);
+                v1 = fmaxf(v1, v1 * a.slope);
+                v2 = fmaxf(v2, v2 * a.slope);
+                v3 = fmaxf(v3, v3 * a.slope);
                 store4<Tag>(wl, (size_t)(r * RECP) / ES + cl, v0, v1, v2, v3);
             }
         }
@@ -336,13 +335,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_zcol(
     constexpr int ES = 16 / G;
     constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
     constexpr int HXP = (TX == 32 || !PADX) ? HX : (HX + 15) / 16 * 16 + (TX % 16);  // row stride (slots)
-    constexpr int HV = HZ * HY * HX;       // real halo voxels (staging items per group)
     constexpr int HVP = HZ * HY * HXP;     // slots per channel group
     constexpr int NWAVES = WAVES_M * WAVES_N;
     constexpr int NTHREADS = NWAVES * 64;
     constexpr int YXT = TY * TX / 32;      // 32-voxel (y, x) groups per plane
     constexpr int MT = TZ * YXW;
-    constexpr int NITEMS = (2 * HV + NTHREADS - 1) / NTHREADS;
+    constexpr int NCOL = HY * HX;          // (y, x) columns of the halo block
+    constexpr int NITEMS = 2 * HZ;         // staging pieces per thread: one column, 2 groups x HZ planes
     constexpr int RECB = NT * 32 * ES;
     constexpr int RECP = RECB + 16;  // padded LDS stride of the output transposition
     constexpr int EPI_UNITS = NWAVES * 32 * RECP / 16;
@@ -352,6 +351,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_zcol(
     constexpr int LDS_UNITS = XUNITS + WUNITS;
     static_assert(TY * TX % 32 == 0 && YXT == WAVES_M * YXW, "plane not covered by the waves");
     static_assert(!WLDS || WAVES_N == 1, "LDS weights assume one cout slice per workgroup");
+    static_assert(NCOL <= NTHREADS, "one halo column per thread");
 
     __shared__ __attribute__((aligned(16))) uint4 lds[LDS_UNITS];
 
@@ -361,7 +361,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_zcol(
     const int wm = wave / WAVES_N;
     const int wn = wave % WAVES_N;
     const int half = lane >> 5;
-    const int r = lane & 31;
+    // Voxel of the 32-group this lane works on. With 16-wide rows the group is two
+    // rows whose LDS slots differ by HXP; taking the second row's x in rotated
+    // order, x = (i - HXP) mod 16, puts lane 16+i on bank slot i (mod 16), the
+    // complement of what its ds_read_b128 lane group already uses: no conflicts.
+    const int r = (TX == 16 && (lane & 16)) ? 16 + (((lane & 15) - HXP) & 15) : (lane & 31);
 
     int bid;
     {
@@ -386,30 +390,35 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_zcol(
         col[j] = (p / TX) * HXP + (p % TX) + half * HVP;
     }
 
+    // Column staging: thread t < NCOL owns halo column (hy, hx) = (t / HX, t % HX)
+    // and moves its 2 x HZ pieces. All pieces of a thread share ONE vector offset
+    // (the column inside a plane); plane, channel group and chunk go into the
+    // scalar offset of the buffer load, so staging costs no per-piece VALU work.
     const size_t patch_vox = (size_t)a.d * a.h * a.w;
-    int vidx[NITEMS];   // source voxel of staging item, or -1
-    int slot[NITEMS];   // its LDS slot
-#pragma unroll
-    for (int it = 0; it < NITEMS; ++it) {
-        const int i = tid + it * NTHREADS;
-        const int kg = i >= HV ? 1 : 0;
-        const int hv = i - kg * HV;
-        const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
-        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-        const bool inr = i < 2 * HV;
-        const bool ok = inr && (unsigned)gz < (unsigned)a.d && (unsigned)gy < (unsigned)a.h &&
-                        (unsigned)gx < (unsigned)a.w;
-        vidx[it] = ok ? (gz * a.h + gy) * a.w + gx : -1;
-        slot[it] = inr ? kg * HVP + (hz * HY + hy) * HXP + hx : -1;
-    }
+    const int plane_vox = a.h * a.w;
+    const bool colok = tid < NCOL;
+    const int chy = tid / HX, chx = tid % HX;
+    const int cgy = y0 + chy - 1, cgx = x0 + chx - 1;
+    const bool col_in = colok && (unsigned)cgy < (unsigned)a.h && (unsigned)cgx < (unsigned)a.w;
+    const int colvox = cgy * a.w + cgx;        // voxel of the column inside a plane
+    const int colslot = chy * HXP + chx;       // its LDS slot inside a plane
+    // weight fragments: piece i = tid + it * NTHREADS is element (i & 63) of tap i >> 6
+    const unsigned wvoff = (((tid >> 6) * ntiles) * 64 + (tid & 63)) * 16u;
 
+    // accumulators start from the folded bias: register 4q+k of a lane is channel
+    // 8q + 4*half + k of its slice (no bias pass in the epilogue)
     f32x16 acc[MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int q = 0; q < 4; ++q) {
+            const float4 b = *reinterpret_cast<const float4*>(a.bias + (ntile0 + nt) * 32 + 8 * q + 4 * half);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+            for (int mt = 0; mt < MT; ++mt) {
+                acc[mt][nt][4 * q + 0] = b.x; acc[mt][nt][4 * q + 1] = b.y;
+                acc[mt][nt][4 * q + 2] = b.z; acc[mt][nt][4 * q + 3] = b.w;
+            }
+        }
 
     const int nchunks = (a.ca + a.cb) / KC;
     uint4 stg[NITEMS + WITEMS];  // halo pieces, then weight fragments
@@ -426,29 +435,38 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_zcol(
         const unsigned rowb = cs * ES;  // bytes of one voxel record of this source
         const __amdgpu_buffer_rsrc_t rsrc =
             make_rsrc(src + (size_t)nb * patch_vox * rowb, patch_vox * rowb);
+        const unsigned voff = col_in ? (unsigned)colvox * rowb : kOutOfRange;
+        const unsigned planeb = (unsigned)plane_vox * rowb;
 #pragma unroll
-        for (int it = 0; it < NITEMS; ++it) {
-            const int i = tid + it * NTHREADS;
-            const unsigned voff = vidx[it] >= 0 ? (unsigned)vidx[it] * rowb + (i >= HV ? 16u : 0u)
-                                                : kOutOfRange;
-            stg[it] = buf_load16(rsrc, voff, ch0 * ES);
+        for (int hz = 0; hz < HZ; ++hz) {
+            const int gz = z0 + hz - 1;           // wave-uniform
+            const bool zin = (unsigned)gz < (unsigned)a.d;
+#pragma unroll
+            for (int kg = 0; kg < 2; ++kg)
+                stg[kg * HZ + hz] = zin ? buf_load16(rsrc, voff, (unsigned)gz * planeb + ch0 * ES + kg * 16)
+                                        : make_uint4(0, 0, 0, 0);
         }
         if (WLDS) {
             const __amdgpu_buffer_rsrc_t wrsrc =
                 make_rsrc(a.weights, (size_t)nchunks * 27 * ntiles * 1024);
 #pragma unroll
             for (int it = 0; it < WITEMS; ++it) {
-                const int i = tid + it * NTHREADS;
-                const int tap = i / (NT * 64), rest = i % (NT * 64);
-                const unsigned voff = i < WUNITS ? ((tap * ntiles + ntile0) * 64 + rest) * 16u : kOutOfRange;
-                stg[NITEMS + it] = buf_load16(wrsrc, voff, c * 27 * ntiles * 1024);
+                // taps it * NWAVES + wave; the last round covers taps < 27 only
+                const bool live = it * NWAVES + wave < 27;
+                stg[NITEMS + it] = live ? buf_load16(wrsrc, wvoff,
+                                                     ((c * 27 + it * NWAVES) * ntiles + ntile0) * 1024)
+                                        : make_uint4(0, 0, 0, 0);
             }
         }
     };
     auto stage_store = [&]() {
+        if (colok) {
 #pragma unroll
-        for (int it = 0; it < NITEMS; ++it)
-            if (slot[it] >= 0) lds[slot[it]] = stg[it];
+            for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+                for (int hz = 0; hz < HZ; ++hz)
+                    lds[kg * HVP + hz * HY * HXP + colslot] = stg[kg * HZ + hz];
+        }
         if (WLDS) {
 #pragma unroll
             for (int it = 0; it < WITEMS; ++it) {
@@ -527,10 +545,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_zcol(
         // partial dot product per output, completed by the other half-wave.
         static_assert(HEAD == 0 || NT == 1, "the fused head needs the whole 32-channel record");
         float hw[HEAD > 0 ? HEAD : 1][16];
-        float4 bq4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            bq4[q] = *reinterpret_cast<const float4*>(a.bias + 8 * q + 4 * half);
 #pragma unroll
             for (int o = 0; o < HEAD; ++o) {
                 const float4 t = *reinterpret_cast<const float4*>(a.head_w + o * 32 + 8 * q + 4 * half);
@@ -550,11 +566,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_zcol(
             for (int o = 0; o < HEAD; ++o) part[o] = 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float bb[4] = {bq4[q].x, bq4[q].y, bq4[q].z, bq4[q].w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    float v = acc[mt][0][4 * q + k] + bb[k];
-                    v = v > 0.f ? v : v * a.slope;
+                    float v = acc[mt][0][4 * q + k];
+                    v = fmaxf(v, v * a.slope);
 #pragma unroll
                     for (int o = 0; o < HEAD; ++o) part[o] = fmaf(v, hw[o][4 * q + k], part[o]);
                 }
@@ -576,12 +591,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_zcol(
 
     // ---- epilogue: bias + LeakyReLU, transposed through LDS ------------------
     char* wl = reinterpret_cast<char*>(lds) + wave * (32 * RECP);
-    float4 bq[NT][4];  // bias before the stores (vmcnt counts stores on gfx950)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            bq[nt][q] = *reinterpret_cast<const float4*>(a.bias + ntile0 * 32 + nt * 32 + 8 * q + 4 * half);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int j = mt / TZ, z = mt % TZ;
@@ -590,15 +599,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_zcol(
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int cl = nt * 32 + 8 * q + 4 * half;
-                const float4 b = bq[nt][q];
-                float v0 = acc[mt][nt][4 * q + 0] + b.x;
-                float v1 = acc[mt][nt][4 * q + 1] + b.y;
-                float v2 = acc[mt][nt][4 * q + 2] + b.z;
-                float v3 = acc[mt][nt][4 * q + 3] + b.w;
-                v0 = v0 > 0.f ? v0 : v0 * a.slope;
-                v1 = v1 > 0.f ? v1 : v1 * a.slope;
-                v2 = v2 > 0.f ? v2 : v2 * a.slope;
-                v3 = v3 > 0.f ? v3 : v3 * a.slope;
+                // LeakyReLU with 0 <= slope <= 1 is max(v, slope * v)
+                float v0 = acc[mt][nt][4 * q + 0], v1 = acc[mt][nt][4 * q + 1];
+                float v2 = acc[mt][nt][4 * q + 2], v3 = acc[mt][nt][4 * q + 3];
+                v0 = fmaxf(v0, v0 * a.slope);
+                v1 = fmaxf(v1, v1 * a.slope);
+                v2 = fmaxf(v2, v2 * a.slope);
+                v3 = fmaxf(v3, v3 * a.slope);
                 store4<Tag>(wl, (size_t)(r * RECP) / ES + cl, v0, v1, v2, v3);
             }
         }
@@ -716,6 +723,7 @@ int launch_conv3x3x3(int dtype, const ConvArgs& a, hipStream_t stream) {
     EXA_CHECK_ARG(a.ca % kc == 0 && a.cb % kc == 0 && a.cout % 32 == 0 && a.ca > 0,
                   "conv: channels (%d,%d)->%d not padded", a.ca, a.cb, a.cout);
     EXA_CHECK_ARG(a.n > 0 && a.d > 0 && a.h > 0 && a.w > 0, "conv: empty input");
+    EXA_CHECK_ARG(a.slope >= 0.f && a.slope <= 1.f, "conv: LeakyReLU slope %g outside [0, 1]", a.slope);
     EXA_CHECK_ARG(!a.head_out || conv_can_fuse_head(a.cout, a.w, a.head_oc),
                   "conv: fused head needs cout 32, w %% 16 == 0, 1..4 outputs");
     {   // the LDS-DMA staging addresses one patch of one source with 32-bit offsets

@@ -127,8 +127,16 @@ __global__ __launch_bounds__(256) void conv_first_kernel(
         const float* base = xp + ((size_t)nb * (d + 2) + zz) * phw + yy * pw + xx;
 #pragma unroll
         for (int ks = 0; ks < 14; ++ks) xv[mt][ks] = base[rel[ks]];
+    }
+    // accumulators start from the folded bias (register 4q+k = channel 8q + 4*half + k)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+    for (int q = 0; q < 4; ++q) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + co_tile + 8 * q + 4 * half);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            acc[mt][4 * q + 0] = b.x; acc[mt][4 * q + 1] = b.y;
+            acc[mt][4 * q + 2] = b.z; acc[mt][4 * q + 3] = b.w;
+        }
     }
 #pragma unroll
     for (int ks = 0; ks < 14; ++ks)
@@ -145,20 +153,14 @@ __global__ __launch_bounds__(256) void conv_first_kernel(
     constexpr int PPV = RECB / 16;
     __shared__ __attribute__((aligned(16))) char tr[4 * 32 * RECP];
     char* wl = tr + wave * (32 * RECP);
-    float4 bq[4];  // bias before the stores (vmcnt counts stores on gfx950)
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-        bq[q] = *reinterpret_cast<const float4*>(bias + co_tile + 8 * q + 4 * half);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int cl = 8 * q + 4 * half;
-            const float4 b = bq[q];
-            float o[4] = {acc[mt][4 * q] + b.x, acc[mt][4 * q + 1] + b.y,
-                          acc[mt][4 * q + 2] + b.z, acc[mt][4 * q + 3] + b.w};
+            float o[4] = {acc[mt][4 * q], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = o[j] > 0.f ? o[j] : o[j] * slope;
+            for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], o[j] * slope);  // LeakyReLU, 0 <= slope <= 1
             char* slot = wl + r * RECP + cl * ES;
             if (G == 4) {
                 *reinterpret_cast<float4*>(slot) = make_float4(o[0], o[1], o[2], o[3]);
