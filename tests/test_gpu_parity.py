@@ -357,3 +357,33 @@ def test_predict_16bit_default_config_vs_reference_golden(dev, golden, cdt, tol)
     assert err.max() < tol
     zero = (got == 0).all(axis=0)
     np.testing.assert_array_equal(zero.all(axis=(1, 2)), g["zero_z"])
+
+
+@pytest.mark.parametrize("name,clip", [("u8", 200), ("i16", 500), ("f32", 123.5), ("u16_sparse", 1000)])
+def test_predict_voxel_dtypes_vs_oracle(dev, oracle, name, clip):
+    """End to end for every voxel dtype the ABI takes (uint8, int16, float32, uint16)."""
+    from aind_exaspim_neuron_segmentation_amd import inference
+
+    vol = _volumes()[name]  # (40, 48, 56)
+    model, sd = make_model(dev)
+    kw = dict(batch_size=4, patch_shape=(32, 32, 32), overlap=(16, 8, 8), trim=4,
+              brightness_clip=clip, normalization_percentiles=(2, 98.5))
+    want = oracle.predict(vol, oracle.OracleModel(sd), **kw)
+    got = inference.predict(vol, model, verbose=False, **kw)
+    err = np.abs(got - want).max()
+    print(f"predict {name}: max|diff| = {err:.3e}")
+    assert err < 1e-5
+    np.testing.assert_array_equal(got == 0, want == 0)
+
+
+def test_predict_rejects_dtype_promoting_clip(dev):
+    from aind_exaspim_neuron_segmentation_amd import inference
+
+    model, _ = make_model(dev)
+    vol = _volumes()["u16"]
+    with pytest.raises(NotImplementedError, match="promotes"):
+        inference.predict(vol, model, brightness_clip=1000.5, patch_shape=(32, 32, 32),
+                          overlap=(8, 8, 8), trim=4, verbose=False)
+    with pytest.raises(TypeError, match="not supported"):
+        inference.predict(vol.astype(np.int64), model, patch_shape=(32, 32, 32),
+                          overlap=(8, 8, 8), trim=4, verbose=False)
