@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libexaspim_affinity.so")
 
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 VOX_U8, VOX_U16, VOX_I16, VOX_F32 = 0, 1, 2, 3
+UP_CONVT = 0x100   # EXASPIM_UP_CONVT: OR into a dtype code for UNet3D(trilinear=False)
 
 DTYPE_CODES = {
     "fp32": DT_F32, "float32": DT_F32, "f32": DT_F32,
@@ -71,7 +72,7 @@ _i32 = ctypes.c_int32
 SIGNATURES = {
     "exaspim_abi_version": (_i32, []),
     "exaspim_last_error": (ctypes.c_char_p, []),
-    "exaspim_unet_param_count": (_sz, [_I32x5, _i32]),
+    "exaspim_unet_param_count": (_sz, [_I32x5, _i32, _i32]),
     "exaspim_unet_packed_bytes": (_sz, [_I32x5, _i32, _i32]),
     "exaspim_unet_pack_weights": (_i32, [_I32x5, _i32, _i32, _vp, _sz, _vp, _sz]),
     "exaspim_unet_create": (_i32, [_I32x5, _i32, _i32, _i32, _vp, _sz, ctypes.POINTER(_vp)]),

@@ -55,10 +55,21 @@ struct ConvLayer {
     size_t p_off = 0;              // offset of this conv's block in params
 };
 
+// ConvTranspose3d(k=2, s=2) of an Up block (UNet3D(trilinear=False))
+struct ConvTLayer {
+    int cin_real = 0, cin = 0;     // real / padded input channels
+    int cout_real = 0, cout = 0;   // real / padded output channels
+    size_t w_off = 0;              // packed weights [chunk][phase 8][tile][lane][16 B]
+    size_t b_off = 0;              // bias, float[cout]
+    size_t p_off = 0;              // offset of (weight, bias) in params
+};
+
 struct UNetPlan {
     int channels[5] = {0, 0, 0, 0, 0};
     int out_channels = 0;
-    int dtype = 0;
+    int dtype = 0;                  // EXASPIM_DT_* (without flags)
+    bool convt = false;             // EXASPIM_UP_CONVT
+    ConvTLayer up[4];               // up1.up .. up4.up (convt only)
     int c0 = 0, c0p = 0;            // inc.0 output channels real / padded
     size_t first_p_off = 0;         // params offset of inc.0
     size_t first_w_off = 0;         // float[27][c0p]
@@ -105,6 +116,9 @@ bool conv_can_fuse_head(int cout, int w, int head_oc);
 int launch_conv_first(int dtype, const float* x, float* xpad, const float* w, const float* bias,
                       void* dst, int n, int d, int h, int wd, int c0p, float slope,
                       hipStream_t stream);
+// ConvTranspose3d(k=2, s=2): (n, d, h, w, cin) -> (n, 2d, 2h, 2w, cout), bias, no activation
+int launch_convt2(int dtype, const void* src, const void* weights, const float* bias, void* dst,
+                  int n, int d, int h, int w, int cin, int cout, hipStream_t stream);
 int launch_maxpool2(int dtype, const void* src, void* dst, int n, int d, int h, int w,
                     int c, hipStream_t stream);  // d,h,w = INPUT size
 int launch_upsample2(int dtype, const void* src, void* dst, int n, int d, int h, int w,

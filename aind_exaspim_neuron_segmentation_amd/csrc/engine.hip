@@ -48,19 +48,22 @@ static bool level_dims_ok(int d, int h, int w) {
     return d > 0 && h > 0 && w > 0 && d % 16 == 0 && h % 16 == 0 && w % 16 == 0;
 }
 
+// pyramid level of the i-th MFMA conv (inc.3 = 0 ... up4.3 = 16)
+static int conv_level(int i) {
+    if (i == 0) return 0;
+    if (i <= 8) return (i + 1) / 2;          // down1..down4 -> 1..4
+    return 3 - (i - 9) / 2;                  // up1..up4 -> 3..0
+}
+
 static Workspace make_workspace(const UNetPlan& p, int n, int d, int h, int w) {
-    const int* c = p.channels;
-    const int c0 = pad_channels(c[0]), c1 = pad_channels(c[1]), c2 = pad_channels(c[2]),
-              c3 = pad_channels(c[3]), h4 = pad_channels(c[4] / 2);
-    const int y1c = pad_channels(c[3] / 2), y2c = pad_channels(c[2] / 2),
-              y3c = pad_channels(c[1] / 2);
-    const int maxc[5] = {
-        std::max(c0, y3c),
-        std::max(std::max(c0, c1), std::max(y2c, y3c)),
-        std::max(std::max(c1, c2), std::max(y1c, y2c)),
-        std::max(std::max(c2, c3), std::max(h4, y1c)),
-        std::max(c3, h4),
-    };
+    // widest tensor stored at each level: every input and output of its convs
+    // (the pooled / upsampled tensors are inputs of the level's first conv)
+    int maxc[5] = {p.c0p, 0, 0, 0, 0};
+    for (int i = 0; i < kNumMfmaConvs; ++i) {
+        const ConvLayer& L = p.conv[i];
+        int& m = maxc[conv_level(i)];
+        m = std::max(m, std::max(std::max(L.ca, L.cb), L.cout));
+    }
     const size_t es = dtype_size(p.dtype);
     Workspace ws;
     size_t off = 0;
@@ -148,8 +151,15 @@ static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, in
     for (int l = 3; l >= 0; --l) {
         const int i0 = 9 + 2 * (3 - l);  // up1.0 = conv[9], up2.0 = conv[11], ...
         const ConvLayer& L0 = p.conv[i0];
-        RUN(launch_upsample2(dt, prev, A(l), n, d >> (l + 1), h >> (l + 1), w >> (l + 1), L0.cb,
-                             stream));
+        if (p.convt) {
+            const ConvTLayer& U = p.up[3 - l];
+            RUN(launch_convt2(dt, prev, e->packed + U.w_off,
+                              reinterpret_cast<const float*>(e->packed + U.b_off), A(l), n,
+                              d >> (l + 1), h >> (l + 1), w >> (l + 1), U.cin, U.cout, stream));
+        } else {
+            RUN(launch_upsample2(dt, prev, A(l), n, d >> (l + 1), h >> (l + 1), w >> (l + 1), L0.cb,
+                                 stream));
+        }
         RUN(conv(i0, skip(l), A(l), B(l), l));
         RUN(conv(i0 + 1, B(l), nullptr, A(l), l));
         prev = A(l);
@@ -169,9 +179,10 @@ using namespace exaspim;
 extern "C" int exaspim_abi_version(void) { return EXASPIM_ABI_VERSION; }
 extern "C" const char* exaspim_last_error(void) { return get_error(); }
 
-extern "C" size_t exaspim_unet_param_count(const int32_t channels[5], int32_t out_channels) {
+extern "C" size_t exaspim_unet_param_count(const int32_t channels[5], int32_t out_channels,
+                                           int32_t dtype) {
     UNetPlan p;
-    if (!make_plan(channels, out_channels, EXASPIM_DT_F32, &p)) return 0;
+    if (!make_plan(channels, out_channels, dtype, &p)) return 0;
     return p.n_params;
 }
 

@@ -186,6 +186,97 @@ __global__ __launch_bounds__(256) void conv_first_kernel(
     }
 }
 
+// ---- ConvTranspose3d(k=2, s=2) ------------------------------------------------
+// Up block of UNet3D(trilinear=False) (unet3d.py:254-258). Kernel 2 with stride
+// 2 has no tap overlap: out[2z+dz, 2y+dy, 2x+dx, :] = b + W[:, :, dz, dy, dx]^T in[z, y, x, :],
+// i.e. eight independent 1x1x1 GEMMs that scatter to the 2x2x2 output phases.
+// One wave takes 32 input voxels x 32 output channels x 8 phases (8 accumulator
+// tiles); the B operand is the voxel's 16-byte channel group straight from
+// global memory (one load feeds the eight MFMAs of a chunk), the A operand the
+// phase's weight fragment (plan.cpp). ~4 % of the 3x3x3 FLOPs of the network.
+typedef float f32x16_ct __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_ct __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_ct __attribute__((ext_vector_type(8)));
+
+template <typename T>
+__device__ __forceinline__ void mma_ct(f32x16_ct& acc, const uint4& wf, const uint4& xf);
+template <>
+__device__ __forceinline__ void mma_ct<F32T>(f32x16_ct& acc, const uint4& wf, const uint4& xf) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wf.x), __uint_as_float(xf.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wf.y), __uint_as_float(xf.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wf.z), __uint_as_float(xf.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wf.w), __uint_as_float(xf.w), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_ct<BF16T>(f32x16_ct& acc, const uint4& wf, const uint4& xf) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_ct, wf),
+                                                  __builtin_bit_cast(bf16x8_ct, xf), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_ct<F16T>(f32x16_ct& acc, const uint4& wf, const uint4& xf) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_ct, wf),
+                                                 __builtin_bit_cast(f16x8_ct, xf), acc, 0, 0, 0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void convt2_kernel(const uint4* __restrict__ src,
+                                                     const uint4* __restrict__ wts,
+                                                     const float* __restrict__ bias,
+                                                     void* __restrict__ dst, int nvox, int d, int h,
+                                                     int w, int cin, int cout) {
+    constexpr int G = T::kG;
+    constexpr int ES = 16 / G;
+    constexpr int KC = 2 * G;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int half = lane >> 5, r = lane & 31;
+    const int ntiles = cout >> 5, ntile = blockIdx.y;
+    const int nchunks = cin / KC;
+    const int v = (blockIdx.x * 4 + wave) * 32 + r;   // input voxel (flat over the batch)
+    const int vc = v < nvox ? v : nvox - 1;
+
+    f32x16_ct acc[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + ntile * 32 + 8 * q + 4 * half);
+#pragma unroll
+        for (int ph = 0; ph < 8; ++ph) {
+            acc[ph][4 * q + 0] = b.x; acc[ph][4 * q + 1] = b.y;
+            acc[ph][4 * q + 2] = b.z; acc[ph][4 * q + 3] = b.w;
+        }
+    }
+    const uint4* xrow = src + (size_t)vc * (cin / G) + half;   // 16-byte groups of this voxel
+    for (int c = 0; c < nchunks; ++c) {
+        const uint4 xf = xrow[2 * c];
+        const uint4* wp = wts + (((size_t)c * 8) * ntiles + ntile) * 64 + lane;
+#pragma unroll
+        for (int ph = 0; ph < 8; ++ph) mma_ct<T>(acc[ph], wp[(size_t)ph * ntiles * 64], xf);
+    }
+    if (v >= nvox) return;
+    const int hw = h * w, dhw = d * hw;
+    const int nb = v / dhw, sp = v - nb * dhw;
+    const int z = sp / hw, y = (sp - z * hw) / w, x = sp - z * hw - y * w;
+    const int oh = 2 * h, ow = 2 * w;
+#pragma unroll
+    for (int ph = 0; ph < 8; ++ph) {
+        const size_t ovox = (((size_t)nb * 2 * d + 2 * z + (ph >> 2)) * oh + 2 * y + ((ph >> 1) & 1)) * ow +
+                            2 * x + (ph & 1);
+        char* orec = static_cast<char*>(dst) + (ovox * cout + ntile * 32) * ES;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float o4[4] = {acc[ph][4 * q], acc[ph][4 * q + 1], acc[ph][4 * q + 2], acc[ph][4 * q + 3]};
+            char* out = orec + (8 * q + 4 * half) * ES;
+            if (G == 4) {
+                *reinterpret_cast<float4*>(out) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+            } else {
+                float o8[8] = {o4[0], o4[1], o4[2], o4[3], 0.f, 0.f, 0.f, 0.f};
+                const uint4 pk = T::pack(o8);
+                *reinterpret_cast<uint2*>(out) = make_uint2(pk.x, pk.y);
+            }
+        }
+    }
+}
+
 // ---- max-pool 2x2x2 ----------------------------------------------------------
 // Grid: x = 16-byte pieces of one output row, y = output row, z = patch * depth.
 // All per-thread index arithmetic is 32-bit; the row/plane split is scalar.
@@ -330,6 +421,19 @@ int launch_conv_first(int dtype, const float* x, float* xpad, const float* w, co
     EXA_CHECK_HIP(hipGetLastError());
     dim3 grid((unsigned)blocks, c0p / 32);
     DISPATCH_T(dtype, (conv_first_kernel<T, MT><<<grid, 256, 0, stream>>>(xpad, w, bias, dst, (int)nvox, d, h, wd, c0p, slope)));
+    EXA_CHECK_HIP(hipGetLastError());
+    return EXASPIM_OK;
+}
+
+int launch_convt2(int dtype, const void* src, const void* weights, const float* bias, void* dst,
+                  int n, int d, int h, int w, int cin, int cout, hipStream_t stream) {
+    const size_t nvox = (size_t)n * d * h * w;
+    EXA_CHECK_ARG(nvox > 0 && nvox < 0x7fffffffULL && cin % 32 == 0 && cout % 32 == 0,
+                  "convt: bad size (%zu voxels, %d -> %d channels)", nvox, cin, cout);
+    dim3 grid((unsigned)((nvox + 127) / 128), cout / 32);
+    DISPATCH_T(dtype, (convt2_kernel<T><<<grid, 256, 0, stream>>>(
+                          static_cast<const uint4*>(src), static_cast<const uint4*>(weights), bias,
+                          dst, (int)nvox, d, h, w, cin, cout)));
     EXA_CHECK_HIP(hipGetLastError());
     return EXASPIM_OK;
 }

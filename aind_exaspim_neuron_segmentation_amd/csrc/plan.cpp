@@ -47,6 +47,8 @@ bool make_plan(const int32_t channels[5], int32_t out_channels, int32_t dtype,
         set_error("channels[1..4] must be even (trilinear U-Net halves them)");
         return false;
     }
+    const bool convt = (dtype & EXASPIM_UP_CONVT) != 0;
+    dtype &= 0xff;
     if (channels[3] != channels[4] / 2 || channels[2] != channels[3] / 2 ||
         channels[1] != channels[2] / 2 || channels[0] != channels[1] / 2) {
         set_error("channels must double per level (skip + upsampled = next width)");
@@ -64,8 +66,11 @@ bool make_plan(const int32_t channels[5], int32_t out_channels, int32_t dtype,
     for (int i = 0; i < 5; ++i) p.channels[i] = channels[i];
     p.out_channels = out_channels;
     p.dtype = dtype;
+    p.convt = convt;
     const int* c = channels;
-    const int half4 = c[4] / 2;
+    // trilinear U-Net halves the bottleneck and the decoder widths (factor 2,
+    // unet3d.py:53,68-74); the ConvTranspose3d variant keeps them (factor 1)
+    const int half4 = convt ? c[4] : c[4] / 2;
 
     // (ca_real, cb_real, cout_real) of the 17 MFMA convs in state_dict order
     // (unet3d.py:64-74; Up: DoubleConv(in, out, mid=in//2) on cat[skip, up]).
@@ -76,10 +81,13 @@ bool make_plan(const int32_t channels[5], int32_t out_channels, int32_t dtype,
         {c[1], 0, c[2]}, {c[2], 0, c[2]},                 // down2
         {c[2], 0, c[3]}, {c[3], 0, c[3]},                 // down3
         {c[3], 0, half4}, {half4, 0, half4},              // down4
-        {c[3], half4, c[4] / 2}, {c[4] / 2, 0, c[3] / 2}, // up1: cat[x4, up(x5)]
-        {c[2], c[3] / 2, c[3] / 2}, {c[3] / 2, 0, c[2] / 2},  // up2
-        {c[1], c[2] / 2, c[2] / 2}, {c[2] / 2, 0, c[1] / 2},  // up3
-        {c[0], c[1] / 2, c[1] / 2}, {c[1] / 2, 0, c[0]},      // up4
+        // Up blocks on cat[skip, up(prev)]. trilinear: DoubleConv(in, out/2, mid=in/2);
+        // conv-transpose: up halves the channels first, DoubleConv(in, out) (mid = out)
+        {c[3], convt ? c[4] / 2 : half4, convt ? c[3] : c[4] / 2},
+        {convt ? c[3] : c[4] / 2, 0, convt ? c[3] : c[3] / 2},                      // up1
+        {c[2], c[3] / 2, convt ? c[2] : c[3] / 2}, {convt ? c[2] : c[3] / 2, 0, convt ? c[2] : c[2] / 2},  // up2
+        {c[1], c[2] / 2, convt ? c[1] : c[2] / 2}, {convt ? c[1] : c[2] / 2, 0, convt ? c[1] : c[1] / 2},  // up3
+        {c[0], c[1] / 2, convt ? c[0] : c[1] / 2}, {convt ? c[0] : c[1] / 2, 0, c[0]},                     // up4
     };
 
     size_t poff = 0, woff = 0;
@@ -93,6 +101,20 @@ bool make_plan(const int32_t channels[5], int32_t out_channels, int32_t dtype,
     p.first_b_off = woff;
     woff = align_up(woff + (size_t)p.c0p * sizeof(float), 256);
     for (int i = 0; i < kNumMfmaConvs; ++i) {
+        if (convt && i >= 9 && (i - 9) % 2 == 0) {
+            // upN.up.weight (Cin, Cin/2, 2, 2, 2) + bias come before the block's DoubleConv
+            ConvTLayer& U = p.up[(i - 9) / 2];
+            U.cin_real = c[4 - (i - 9) / 2];
+            U.cout_real = U.cin_real / 2;
+            U.cin = pad_channels(U.cin_real);
+            U.cout = pad_channels(U.cout_real);
+            U.p_off = poff;
+            poff += (size_t)U.cin_real * U.cout_real * 8 + U.cout_real;
+            U.w_off = woff;
+            woff = align_up(woff + (size_t)8 * U.cin * U.cout * es, 256);
+            U.b_off = woff;
+            woff = align_up(woff + (size_t)U.cout * sizeof(float), 256);
+        }
         ConvLayer& L = p.conv[i];
         L.ca_real = specs[i].ca;
         L.cb_real = specs[i].cb;
@@ -215,6 +237,41 @@ int pack_weights(const UNetPlan& plan, const float* params, void* packed_host) {
                             }
                         }
                     }
+    }
+
+    if (plan.convt) {
+        // ConvTranspose3d(k=2, s=2): out[2z+dz, 2y+dy, 2x+dx, co] = b[co] + sum_ci in[z,y,x,ci] *
+        // W[ci][co][dz][dy][dx] -- eight 1x1x1 GEMMs; fragments [chunk][phase][tile][lane]
+        for (int u = 0; u < 4; ++u) {
+            const ConvTLayer& U = plan.up[u];
+            const float* w = params + U.p_off;
+            const float* bsrc = w + (size_t)U.cin_real * U.cout_real * 8;
+            float* b = reinterpret_cast<float*>(out + U.b_off);
+            for (int o = 0; o < U.cout_real; ++o) b[o] = bsrc[o];
+            const int nchunks = U.cin / KC, ntiles = U.cout / 32;
+            for (int c = 0; c < nchunks; ++c)
+                for (int ph = 0; ph < 8; ++ph)
+                    for (int n = 0; n < ntiles; ++n)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int co = 32 * n + (lane & 31);
+                            const size_t frag = (((size_t)c * 8 + ph) * ntiles + n) * 64 + lane;
+                            for (int j = 0; j < G; ++j) {
+                                const int ci = KC * c + G * (lane >> 5) + j;
+                                float v = 0.f;
+                                if (ci < U.cin_real && co < U.cout_real)
+                                    v = w[((size_t)ci * U.cout_real + co) * 8 + ph];
+                                char* dst = out + U.w_off + (frag * G + j) * es;
+                                if (plan.dtype == EXASPIM_DT_F32) {
+                                    std::memcpy(dst, &v, 4);
+                                } else {
+                                    const uint16_t hbits = plan.dtype == EXASPIM_DT_BF16
+                                                               ? f32_to_bf16_rne(v)
+                                                               : f32_to_f16_rne(v);
+                                    std::memcpy(dst, &hbits, 2);
+                                }
+                            }
+                        }
+        }
     }
 
     {  // head: float [out_channels][c0p] + float[out_channels] (unet3d.py:318)

@@ -8,10 +8,10 @@ the reference's trainer (train.py:286) load unchanged with
 ``load_state_dict(strict=True)``. No torch operator runs in ``forward``: the
 parameters are BatchNorm-folded and packed once by the C-ABI extension, and
 the whole network (3x3x3 convs on the matrix cores, max-pool, trilinear
-upsampling, skip concatenation, 1x1x1 head) executes as hand-written gfx950
+upsampling or 2x2x2 transposed convolution, skip concatenation, 1x1x1 head) executes as hand-written gfx950
 kernels on the caller's HIP stream (csrc/engine.hip).
 
-Inference only (eval-mode BatchNorm, ``trilinear=True``); there is no CPU
+Inference only (eval-mode BatchNorm; both ``trilinear`` variants); there is no CPU
 path -- calling the model with a CPU tensor raises.
 """
 
@@ -41,6 +41,18 @@ class _ConvParams(nn.Module):
         self.weight = nn.Parameter(torch.empty(cout, cin, k, k, k))
         self.bias = nn.Parameter(torch.empty(cout))
         bound = 1.0 / math.sqrt(cin * k ** 3)
+        nn.init.uniform_(self.weight, -bound, bound)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class _ConvTransposeParams(nn.Module):
+    """Weight (in, out, k, k, k) and bias of one nn.ConvTranspose3d."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cin, cout, k, k, k))
+        self.bias = nn.Parameter(torch.empty(cout))
+        bound = 1.0 / math.sqrt(cout * k ** 3)   # torch's fan_in of a transposed conv
         nn.init.uniform_(self.weight, -bound, bound)
         nn.init.uniform_(self.bias, -bound, bound)
 
@@ -77,7 +89,8 @@ class UNet3D(nn.Module):
     output_channels : int, optional
         Number of channels in the output. Default is 1.
     trilinear : bool, optional
-        Must be True (the only variant load_model of the reference creates).
+        True (default; the variant load_model of the reference creates) for
+        trilinear upsampling, False for ConvTranspose3d(k=2, s=2) up blocks.
     width_multiplier : float, optional
         Factor that scales the number of channels in each layer. Default is 1.
     compute_dtype : str, optional
@@ -94,10 +107,15 @@ class UNet3D(nn.Module):
         self.trilinear = trilinear
         self.output_channels = output_channels
         self.compute_dtype = compute_dtype
-        blocks, (head_in, head_out) = unet_layer_specs(
+        layers, (head_in, head_out) = unet_layer_specs(
             output_channels, trilinear, width_multiplier
         )
-        for prefix, cin, cmid, cout in blocks:
+        for kind, prefix, *widths in layers:
+            if kind == "conv_transpose":
+                cin, cout = widths
+                _attach(self, prefix, _ConvTransposeParams(cin, cout, 2))
+                continue
+            cin, cmid, cout = widths
             _attach(self, f"{prefix}.0", _ConvParams(cin, cmid, 3))
             _attach(self, f"{prefix}.1", _NormParams(cmid))
             _attach(self, f"{prefix}.3", _ConvParams(cmid, cout, 3))
@@ -145,8 +163,10 @@ class UNet3D(nn.Module):
         lib = _native.lib()
         ch = _native.channels_array(self.channels)
         code = _native.DTYPE_CODES[self.compute_dtype]
+        if not self.trilinear:
+            code |= _native.UP_CONVT
         params = self._canonical_params()
-        expected = lib.exaspim_unet_param_count(ch, self.output_channels)
+        expected = lib.exaspim_unet_param_count(ch, self.output_channels, code)
         if expected == 0:
             raise ValueError(f"unsupported network: {_native.last_error()}")
         if params.size != expected:

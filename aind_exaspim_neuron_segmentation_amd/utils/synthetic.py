@@ -93,10 +93,10 @@ def _uniform01(key, n, seed):
     return (h >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
 
 
-def synth_state_dict(output_channels=3, width_multiplier=1, seed=1):
+def synth_state_dict(output_channels=3, width_multiplier=1, seed=1, trilinear=True):
     """
     Builds a synthetic UNet3D state_dict (numpy arrays) with the reference's
-    128 keys in the reference's order.
+    keys in the reference's order (128 keys; 136 with "trilinear=False").
 
     Parameters
     ----------
@@ -106,14 +106,17 @@ def synth_state_dict(output_channels=3, width_multiplier=1, seed=1):
         Channel width factor. Default is 1.
     seed : int, optional
         Seed of the value streams. Default is 1.
+    trilinear : bool, optional
+        False selects the ConvTranspose3d variant of the Up blocks. Default is
+        True.
 
     Returns
     -------
     Dict[str, numpy.ndarray]
         float32 arrays (int64 scalars for "num_batches_tracked").
     """
-    blocks, (head_in, head_out) = unet_layer_specs(
-        output_channels, True, width_multiplier
+    layers, (head_in, head_out) = unet_layer_specs(
+        output_channels, trilinear, width_multiplier
     )
     sd = {}
 
@@ -122,7 +125,14 @@ def synth_state_dict(output_channels=3, width_multiplier=1, seed=1):
         u = _uniform01(key, n, seed)
         return (lo + (hi - lo) * u).astype(np.float32).reshape(shape)
 
-    for prefix, cin, cmid, cout in blocks:
+    for layer in layers:
+        if layer[0] == "conv_transpose":
+            _, prefix, cin, cout = layer
+            bound = 1.0 / np.sqrt(float(cin))
+            sd[f"{prefix}.weight"] = uni(f"{prefix}.weight", (cin, cout, 2, 2, 2), -bound, bound)
+            sd[f"{prefix}.bias"] = uni(f"{prefix}.bias", (cout,), -bound, bound)
+            continue
+        _, prefix, cin, cmid, cout = layer
         for conv_idx, bn_idx, ci, co in ((0, 1, cin, cmid), (3, 4, cmid, cout)):
             bound = 1.0 / np.sqrt(27.0 * ci)
             k = f"{prefix}.{conv_idx}"

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EXASPIM_ABI_VERSION 1
+#define EXASPIM_ABI_VERSION 2
 
 /* error codes */
 #define EXASPIM_OK 0
@@ -45,6 +45,12 @@ extern "C" {
 #define EXASPIM_DT_F32 0  /* exact f32 MFMA (v_mfma_f32_32x32x2_f32)        */
 #define EXASPIM_DT_BF16 1 /* bf16 storage, v_mfma_f32_32x32x16_bf16         */
 #define EXASPIM_DT_F16 2  /* f16 storage,  v_mfma_f32_32x32x16_f16          */
+/* OR-ed into "dtype" wherever a network is described: the Up blocks use
+ * ConvTranspose3d(k=2, s=2) instead of trilinear upsampling, i.e. the
+ * reference's UNet3D(trilinear=False) (unet3d.py:254-258; 136 state_dict
+ * tensors, "upN.up.weight (Cin, Cin/2, 2, 2, 2)" and "upN.up.bias" precede each
+ * block's DoubleConv in the canonical parameter order). */
+#define EXASPIM_UP_CONVT 0x100
 
 /* voxel dtype of an input volume */
 #define EXASPIM_VOX_U8 0
@@ -76,14 +82,20 @@ int exaspim_abi_version(void);
 const char* exaspim_last_error(void);
 
 /* ---- model: replaces load_model() / UNet3D (inference.py:400-424,
- *      machine_learning/unet3d.py:16-336; trilinear=True only) ------------ */
+ *      machine_learning/unet3d.py:16-336). Every "dtype" argument is one of
+ *      EXASPIM_DT_*, optionally OR-ed with EXASPIM_UP_CONVT to select the
+ *      UNet3D(trilinear=False) variant whose Up blocks use
+ *      ConvTranspose3d(k=2, s=2) (unet3d.py:254-258) ---------------------- */
 
 /* Number of float32 values in the canonical parameter vector for a UNet3D
  * with level widths channels[0..4] (unet3d.py:56) and "out_channels" head
  * outputs: the state_dict tensors in state_dict order, "num_batches_tracked"
  * skipped, i.e. per conv: weight(Cout,Cin,3,3,3), bias, bn.weight, bn.bias,
- * bn.running_mean, bn.running_var; finally outc.conv.weight, outc.conv.bias. */
-size_t exaspim_unet_param_count(const int32_t channels[5], int32_t out_channels);
+ * bn.running_mean, bn.running_var; with EXASPIM_UP_CONVT each Up block is
+ * preceded by up.weight(Cin,Cin/2,2,2,2), up.bias; finally outc.conv.weight,
+ * outc.conv.bias. Only the EXASPIM_UP_CONVT bit of "dtype" matters here. */
+size_t exaspim_unet_param_count(const int32_t channels[5], int32_t out_channels,
+                                int32_t dtype);
 
 /* Size of the packed device image of the weights for a compute dtype. */
 size_t exaspim_unet_packed_bytes(const int32_t channels[5], int32_t out_channels,

@@ -126,11 +126,17 @@ def down(x, sd, name):
 
 
 def up(x1, x2, sd, name):
-    """Follows Up (trilinear=True), unet3d.py:247-253,280-289, including the
-    2-D leftover padding rule (depth is never padded)."""
-    x1 = F.interpolate(
-        x1, scale_factor=2, mode="trilinear", align_corners=True
-    )
+    """Follows Up, unet3d.py:247-258,280-289 (trilinear upsampling, or
+    ConvTranspose3d(k=2, s=2) when the state_dict carries "<name>.up.weight"),
+    including the 2-D leftover padding rule (depth is never padded)."""
+    if f"{name}.up.weight" in sd:
+        x1 = F.conv_transpose3d(
+            x1, _t(sd, f"{name}.up.weight"), _t(sd, f"{name}.up.bias"), stride=2
+        )
+    else:
+        x1 = F.interpolate(
+            x1, scale_factor=2, mode="trilinear", align_corners=True
+        )
     diff_y = x2.size()[2] - x1.size()[2]
     diff_x = x2.size()[3] - x1.size()[3]
     x1 = F.pad(

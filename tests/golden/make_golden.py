@@ -257,11 +257,32 @@ def g6_default_config():
     )
 
 
+def g7_conv_transpose_variant():
+    """UNet3D(trilinear=False): ConvTranspose3d(k=2, s=2) in the Up blocks
+    (unet3d.py:254-258) -- full-width forward on 32^3 patches and a small predict."""
+    sd = synthetic.synth_state_dict(3, 1, seed=8, trilinear=False)
+    model = RefUNet3D(output_channels=3, trilinear=False)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    model.eval()
+    assert len(sd) == 136
+    vols = [synthetic.synth_volume((32, 32, 48), seed=60 + i) for i in range(2)]
+    x = np.stack([ref_img.normalize(np.minimum(v, 1000)) for v in vols])[:, None]
+    with torch.no_grad():
+        logits = model(torch.tensor(x.astype(np.float32)))
+    vol = synthetic.synth_volume((56, 40, 48), seed=61)
+    pred = ref_inf.predict(vol, model, batch_size=3, patch_shape=(32, 32, 32),
+                           overlap=(8, 8, 8), trim=4, verbose=False)
+    save("g7_conv_transpose.npz", logits_sub=logits[:, :, ::2, ::2, ::2].numpy().copy(),
+         logits_row=logits[1, :, 17, 9, :].numpy().copy(),
+         pred_sub=pred[:, ::2, ::2, ::2].copy())
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g2b", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g2b", "g3", "g4", "g5", "g6", "g7"]
     table = dict(g1=g1_patch_starts, g2=g2_normalize, g2b=g2b_padding,
                  g3=g3_tiny_predict, g4=g4_single_patch,
-                 g5=g5_fullwidth_small_patches, g6=g6_default_config)
+                 g5=g5_fullwidth_small_patches, g6=g6_default_config,
+                 g7=g7_conv_transpose_variant)
     for w in which:
         table[w]()

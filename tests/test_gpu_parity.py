@@ -32,11 +32,12 @@ def oracle():
     return reference_path
 
 
-def make_model(dev, out_channels=3, seed=1, compute_dtype="fp32"):
+def make_model(dev, out_channels=3, seed=1, compute_dtype="fp32", trilinear=True):
     from aind_exaspim_neuron_segmentation_amd.machine_learning.unet3d import UNet3D
 
-    sd = synthetic.synth_state_dict(out_channels, 1, seed=seed)
-    model = UNet3D(output_channels=out_channels, compute_dtype=compute_dtype)
+    sd = synthetic.synth_state_dict(out_channels, 1, seed=seed, trilinear=trilinear)
+    model = UNet3D(output_channels=out_channels, trilinear=trilinear,
+                   compute_dtype=compute_dtype)
     model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
     return model.to(dev).eval(), sd
 
@@ -85,6 +86,52 @@ def test_unet_16bit_paths_vs_oracle(dev, oracle, cdt, tol):
     err = np.abs(got - want)
     print(f"{cdt} probabilities: max {err.max():.3e} mean {err.mean():.3e}")
     assert err.max() < tol
+
+
+def test_conv_transpose_variant_vs_reference_golden_and_oracle(dev, oracle, golden):
+    """UNet3D(trilinear=False): ConvTranspose3d(k=2, s=2) up blocks (unet3d.py:254-258)."""
+    from aind_exaspim_neuron_segmentation_amd import inference
+
+    g = golden("g7_conv_transpose.npz")
+    model, sd = make_model(dev, seed=8, trilinear=False)
+    x = normalized_input(oracle, (32, 32, 48), seed=60, n=2)
+    got = model(x.to(dev)).cpu().numpy()
+    want = oracle.unet_forward(x, oracle.OracleModel(sd).sd).numpy()
+    e_ref = max(np.abs(got[:, :, ::2, ::2, ::2] - g["logits_sub"]).max(),
+                np.abs(got[1, :, 17, 9, :] - g["logits_row"]).max())
+    e_orc = np.abs(got - want).max()
+    print(f"convT fp32 logits: vs reference {e_ref:.3e}, vs oracle {e_orc:.3e}")
+    assert e_ref < 1e-4 and e_orc < 1e-4
+    vol = synthetic.synth_volume((56, 40, 48), seed=61)
+    pred = inference.predict(vol, model, batch_size=3, patch_shape=(32, 32, 32),
+                             overlap=(8, 8, 8), trim=4, verbose=False)
+    e_pred = np.abs(pred[:, ::2, ::2, ::2] - g["pred_sub"]).max()
+    print(f"convT fp32 predict vs reference: {e_pred:.3e}")
+    assert e_pred < 1e-5
+
+
+@pytest.mark.parametrize("cdt,tol", [("bf16", 2e-2), ("fp16", 2e-3)])
+def test_conv_transpose_variant_16bit(dev, oracle, cdt, tol):
+    model, sd = make_model(dev, seed=8, compute_dtype=cdt, trilinear=False)
+    x = normalized_input(oracle, (32, 32, 32), seed=62, n=3)
+    want = torch.sigmoid(oracle.unet_forward(x, oracle.OracleModel(sd).sd)).numpy()
+    got = model.run(x.to(dev), apply_sigmoid=True).cpu().numpy()
+    err = np.abs(got - want)
+    print(f"convT {cdt} probabilities: max {err.max():.3e} mean {err.mean():.3e}")
+    assert err.max() < tol
+
+
+def test_conv_transpose_half_width(dev, oracle):
+    from aind_exaspim_neuron_segmentation_amd.machine_learning.unet3d import UNet3D
+
+    sd = synthetic.synth_state_dict(1, 0.5, seed=4, trilinear=False)
+    model = UNet3D(output_channels=1, trilinear=False, width_multiplier=0.5)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    model = model.to(dev).eval()
+    x = normalized_input(oracle, (16, 32, 16), seed=63, n=2)
+    want = oracle.unet_forward(x, oracle.OracleModel(sd).sd).numpy()
+    got = model(x.to(dev)).cpu().numpy()
+    assert np.abs(got - want).max() < 1e-4
 
 
 def test_unet_rejects_bad_inputs(dev):

@@ -33,17 +33,17 @@ def test_header_symbols_are_exported(lib):
     assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.exaspim_abi_version() == 1
+    assert lib.exaspim_abi_version() == 2
 
 
 def test_param_count_matches_state_dict(lib):
     sd = synthetic.synth_state_dict(3, 1, seed=1)
     n = sum(v.size for k, v in sd.items() if not k.endswith("num_batches_tracked"))
     ch = _native.channels_array([32, 64, 128, 256, 512])
-    assert lib.exaspim_unet_param_count(ch, 3) == n == 12951267
-    assert lib.exaspim_unet_param_count(_native.channels_array([4, 8, 16, 32, 64]), 1) > 0
+    assert lib.exaspim_unet_param_count(ch, 3, 0) == n == 12951267
+    assert lib.exaspim_unet_param_count(_native.channels_array([4, 8, 16, 32, 64]), 1, 0) > 0
     # invalid widths are rejected with a message
-    assert lib.exaspim_unet_param_count(_native.channels_array([32, 64, 128, 256, 500]), 3) == 0
+    assert lib.exaspim_unet_param_count(_native.channels_array([32, 64, 128, 256, 500]), 3, 0) == 0
     assert "channels" in _native.last_error()
 
 
@@ -60,7 +60,7 @@ def test_pack_weights_folds_batchnorm_in_fragment_order(lib, dtype, code):
     sd = synthetic.synth_state_dict(3, 0.125, seed=3)
     params = _flat_params(sd)
     ch = _native.channels_array(widths)
-    assert lib.exaspim_unet_param_count(ch, 3) == params.size
+    assert lib.exaspim_unet_param_count(ch, 3, 0) == params.size
     nbytes = lib.exaspim_unet_packed_bytes(ch, 3, code)
     packed = np.zeros(nbytes, np.uint8)
     rc = lib.exaspim_unet_pack_weights(ch, 3, code, params.ctypes.data, params.size,
@@ -112,6 +112,47 @@ def test_pack_weights_folds_batchnorm_in_fragment_order(lib, dtype, code):
                         assert got == np.float32(want)
                     else:
                         assert abs(got - want) <= tol * abs(want) + 1e-30
+
+
+def test_pack_conv_transpose_variant(lib):
+    """EXASPIM_UP_CONVT: parameter order and [chunk][phase][tile][lane][4] fragments
+    of the ConvTranspose3d(k=2, s=2) weights (unet3d.py:254-258)."""
+    for wm, widths in ((1, [32, 64, 128, 256, 512]), (0.25, [8, 16, 32, 64, 128])):
+        sd = synthetic.synth_state_dict(3, wm, seed=5, trilinear=False)
+        assert len(sd) == 136
+        params = _flat_params(sd)
+        ch = _native.channels_array(widths)
+        code = _native.UP_CONVT | _native.DT_F32
+        assert lib.exaspim_unet_param_count(ch, 3, code) == params.size
+        assert lib.exaspim_unet_param_count(ch, 3, 0) != params.size
+        nbytes = lib.exaspim_unet_packed_bytes(ch, 3, code)
+        packed = np.zeros(nbytes, np.uint8)
+        _native.check(lib.exaspim_unet_pack_weights(ch, 3, code, params.ctypes.data, params.size,
+                                                    packed.ctypes.data, nbytes), "pack")
+        img = packed.view(np.float32)
+        # up3.up: (Cin, Cout, 2, 2, 2) = (widths[2], widths[1], 2, 2, 2); locate its
+        # fragment block through lane 0 of chunk 0 / phase 0 (ci = 0..3, co = 0)
+        w = sd["up3.up.weight"]
+        cin, cout = w.shape[:2]
+        assert (cin, cout) == (widths[2], widths[1])
+        cinp, coutp = -(-cin // 32) * 32, -(-cout // 32) * 32
+        key = w[0:4, 0, 0, 0, 0]
+        hits = [i for i in np.flatnonzero(img == key[0]) if np.array_equal(img[i:i + 4], key)]
+        assert len(hits) == 1
+        ntiles = coutp // 32
+        frag = img[hits[0]: hits[0] + (cinp // 8) * 8 * ntiles * 64 * 4].reshape(cinp // 8, 8, ntiles, 64, 4)
+        for c in (0, cinp // 8 - 1):
+            for ph in (0, 5, 7):
+                for n in range(ntiles):
+                    for lane in (0, 31, 32, 63):
+                        for j in range(4):
+                            ci, co = 8 * c + 4 * (lane >> 5) + j, 32 * n + (lane & 31)
+                            want = w[ci, co].reshape(8)[ph] if (ci < cin and co < cout) else 0.0
+                            assert frag[c, ph, n, lane, j] == np.float32(want)
+        # the bias follows, unfolded (a transposed conv has no BatchNorm)
+        b = sd["up3.up.bias"]
+        hits = [i for i in np.flatnonzero(img == b[0]) if np.array_equal(img[i:i + cout], b)]
+        assert len(hits) == 1
 
 
 def test_pack_rejects_wrong_sizes(lib):

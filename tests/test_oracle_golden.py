@@ -159,3 +159,18 @@ def test_full_width_small_patches(golden):
         overlap=(16, 16, 16), trim=2,
     )
     np.testing.assert_allclose(pred1[::2, ::2, ::2], g["pred_fg"], rtol=0, atol=5e-6)
+
+
+def test_conv_transpose_variant(golden):
+    """UNet3D(trilinear=False) of the reference."""
+    g = golden("g7_conv_transpose.npz")
+    sd = synthetic.synth_state_dict(3, 1, seed=8, trilinear=False)
+    vols = [synthetic.synth_volume((32, 32, 48), seed=60 + i) for i in range(2)]
+    x = np.stack([oracle.normalize(np.minimum(v, 1000)) for v in vols])[:, None]
+    logits = oracle.unet_forward(torch.tensor(x.astype(np.float32)), oracle.OracleModel(sd).sd)
+    np.testing.assert_allclose(logits[:, :, ::2, ::2, ::2].numpy(), g["logits_sub"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(logits[1, :, 17, 9, :].numpy(), g["logits_row"], rtol=0, atol=5e-6)
+    vol = synthetic.synth_volume((56, 40, 48), seed=61)
+    pred = oracle.predict(vol, oracle.OracleModel(sd), batch_size=3, patch_shape=(32, 32, 32),
+                          overlap=(8, 8, 8), trim=4)
+    np.testing.assert_allclose(pred[:, ::2, ::2, ::2], g["pred_sub"], rtol=0, atol=5e-6)
