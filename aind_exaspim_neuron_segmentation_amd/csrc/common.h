@@ -107,6 +107,10 @@ struct ConvArgs {
     float* head_out = nullptr;      // float (n, head_oc, d, h, w)
     int head_oc = 0;
     int head_sigmoid = 0;
+#ifdef EXASPIM_TRACE
+    // tools/conv_trace.hip only: 16 x 64-bit cycle stamps per wave (never in the library build)
+    unsigned long long* trace = nullptr;
+#endif
 };
 
 int launch_conv3x3x3(int dtype, const ConvArgs& a, hipStream_t stream);

@@ -314,6 +314,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
     }
 }
 
+// Phase stamps for tools/conv_trace.hip (compiled out of the library).
+#ifdef EXASPIM_TRACE
+#define EXA_TRACE(ev)                                                                          \
+    do {                                                                                       \
+        if (a.trace && lane == 0)                                                              \
+            a.trace[((size_t)blockIdx.x * NWAVES + wave) * 16 + (ev)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define EXA_TRACE(ev) do { } while (0)
+#endif
+
 // ---- conv3x3x3_zcol: z-column tiles ---------------------------------------------------
 // As v3, but a wave owns COLUMNS of the tile: YXW groups of 32 (y, x) positions
 // times all TZ planes (MT = TZ * YXW accumulators). For a fixed in-plane tap
@@ -476,9 +487,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_zcol(
         }
     };
 
+#ifdef EXASPIM_TRACE
+    if (a.trace && lane == 0)
+        a.trace[((size_t)blockIdx.x * NWAVES + wave) * 16 + 15] =
+            ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+            (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
+    EXA_TRACE(0);
     stage_load(0);
+    EXA_TRACE(1);
     stage_store();
     __syncthreads();
+    EXA_TRACE(2);
 
     for (int c = 0; c < nchunks; ++c) {
         const uint4* wp = static_cast<const uint4*>(a.weights) +
@@ -532,10 +552,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_zcol(
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (c < 4) EXA_TRACE(3 + 3 * c);
         __syncthreads();
+        if (c < 4) EXA_TRACE(4 + 3 * c);
         if (more) {
             stage_store();
             __syncthreads();
+            if (c < 3) EXA_TRACE(5 + 3 * c);
         }
     }
 
@@ -629,6 +652,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_zcol(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    EXA_TRACE(14);
 }
 
 template <typename Tag, int TZ, int TY, int TX, int WAVES_M, int WAVES_N, int YXW, int NT, int MINW, int PDG, bool WLDS = false, bool PADX = true, int HEAD = 0>

@@ -1,0 +1,85 @@
+// Diagnostic (not part of the library): runs one 3x3x3 MFMA convolution of the
+// network on synthetic data with EXASPIM_TRACE phase stamps and dumps them, so
+// tools/analyze_trace.py can rebuild a per-CU timeline of where a workgroup's
+// life goes (prologue latency, MFMA loop, barriers, epilogue).
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DEXASPIM_TRACE tools/conv_trace.hip \
+//         aind_exaspim_neuron_segmentation_amd/csrc/plan.cpp -x hip -o tools/conv_trace
+//   tools/conv_trace <ca> <cb> <cout> <edge> <batch> <out.bin>
+#include "../aind_exaspim_neuron_segmentation_amd/csrc/conv3d.hip"
+
+#include <cstdlib>
+#include <vector>
+
+#define CK(x)                                                                    \
+    do {                                                                         \
+        hipError_t e_ = (x);                                                     \
+        if (e_ != hipSuccess) {                                                  \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));              \
+            return 1;                                                            \
+        }                                                                        \
+    } while (0)
+
+int main(int argc, char** argv) {
+    if (argc < 7) return 2;
+    const int ca = atoi(argv[1]), cb = atoi(argv[2]), cout = atoi(argv[3]);
+    const int edge = atoi(argv[4]), n = atoi(argv[5]);
+    const size_t vox = (size_t)n * edge * edge * edge;
+    const int cin = ca + cb, nchunks = cin / 16, ntiles = cout / 32;
+    std::vector<uint16_t> h((size_t)vox * (ca > cb ? ca : cb));
+    uint64_t s = 88172645463325252ull;
+    for (auto& v : h) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        v = 0x3c00 + (uint16_t)(s & 0x1ff);  // bf16 around 0.008..0.03
+    }
+    void *a_dev, *b_dev = nullptr, *w_dev, *dst;
+    float* bias;
+    CK(hipMalloc(&a_dev, vox * ca * 2));
+    CK(hipMemcpy(a_dev, h.data(), vox * ca * 2, hipMemcpyHostToDevice));
+    if (cb) {
+        CK(hipMalloc(&b_dev, vox * cb * 2));
+        CK(hipMemcpy(b_dev, h.data(), vox * cb * 2, hipMemcpyHostToDevice));
+    }
+    const size_t wbytes = (size_t)nchunks * 27 * ntiles * 1024;
+    CK(hipMalloc(&w_dev, wbytes));
+    CK(hipMemcpy(w_dev, h.data(), wbytes, hipMemcpyHostToDevice));
+    CK(hipMalloc(&bias, cout * 4));
+    CK(hipMemset(bias, 0, cout * 4));
+    CK(hipMalloc(&dst, vox * cout * 2));
+    const size_t nwg = (size_t)n * ((edge + 5) / 6) * (edge / 8) * (edge / 16);
+    unsigned long long* trace;
+    const size_t tbytes = nwg * 4 * 16 * 8;
+    CK(hipMalloc(&trace, tbytes));
+    CK(hipMemset(trace, 0, tbytes));
+
+    exaspim::ConvArgs a{};
+    a.src_a = a_dev; a.src_b = b_dev; a.ca = ca; a.cb = cb; a.weights = w_dev; a.bias = bias;
+    a.dst = dst; a.cout = cout; a.n = n; a.d = a.h = a.w = edge; a.slope = 0.01f;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int it = 0; it < 4; ++it) {   // warm-up, untraced
+        if (exaspim::launch_conv3x3x3(EXASPIM_DT_BF16, a, 0)) { fprintf(stderr, "%s\n", exaspim::get_error()); return 1; }
+    }
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int it = 0; it < 10; ++it) exaspim::launch_conv3x3x3(EXASPIM_DT_BF16, a, 0);
+    CK(hipEventRecord(e1, 0));
+    CK(hipDeviceSynchronize());
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double flop = 2.0 * 27 * cin * cout * (double)vox;
+    printf("untraced: %.3f ms per launch, %.1f TFLOP/s\n", ms / 10, flop / (ms / 10 * 1e-3) * 1e-12);
+    a.trace = trace;
+    CK(hipEventRecord(e0, 0));
+    exaspim::launch_conv3x3x3(EXASPIM_DT_BF16, a, 0);
+    CK(hipEventRecord(e1, 0));
+    CK(hipDeviceSynchronize());
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("traced: %.3f ms, %zu workgroups\n", ms, nwg);
+    std::vector<unsigned long long> t(nwg * 64);
+    CK(hipMemcpy(t.data(), trace, tbytes, hipMemcpyDeviceToHost));
+    FILE* f = fopen(argv[6], "wb");
+    if (!f) return 1;
+    fwrite(t.data(), 1, tbytes, f);
+    fclose(f);
+    return 0;
+}
