@@ -4,29 +4,35 @@
 // (machine_learning/unet3d.py:142-149) except inc.0 (Cin = 1, layers.hip), and
 // torch.cat([skip, up], dim=1) (unet3d.py:288) by reading two sources.
 //
-// Layout. Activations are channels-last (N, D, H, W, C) with C padded to 32.
+// Layout. Activations are blocked channels-last: the (padded) channels are cut
+// into chunks of 32 bytes (8 x f32 / 16 x 16-bit = the K of one MFMA step) and
+// every chunk is its own plane, (N, C/chunk, D, H, W, 32 B). A row of voxels of
+// one chunk is contiguous, which is what both sides of the kernel want: the K
+// dimension (27 taps x Cin) is walked chunk by chunk, and the texture addresser
+// handles a load instruction per 64-byte segment, so staging whole halo rows of
+// one chunk costs a quarter of gathering one 16-byte piece per voxel record.
 // One workgroup owns a TZ x TY x TX block of output voxels of one patch and a
-// slice of 32 * NT output channels. The K dimension (27 taps x Cin) is walked in
-// chunks of 32 bytes of input channels (8 x f32 / 16 x 16-bit): per chunk the
-// (TZ+2)(TY+2)(TX+2) halo block sits in LDS as two planes of 16-byte channel
-// groups, [group][halo voxel]; the conv's zero padding comes from range-checked
-// buffer loads that return zeros outside the patch. A wave's MFMA B operand
-// (activations, voxel on the lane) is ONE ds_read_b128 per (tap, 32 voxels):
-// lanes 0-31 read group 0, lanes 32-63 group 1. The A operand is a weight
-// fragment in the order plan.cpp packs (1 KiB per wave-instruction).
+// slice of 32 * NT output channels. Per chunk the (TZ+2)(TY+2)(TX+2) halo block
+// sits in LDS as two planes of 16-byte channel groups, [group][halo voxel]; the
+// conv's zero padding comes from range-checked buffer loads that return zeros
+// outside the patch. A wave's MFMA B operand (activations, voxel on the lane) is
+// ONE ds_read_b128 per (tap, 32 voxels): lanes 0-31 read group 0, lanes 32-63
+// group 1. The A operand is a weight fragment in the order plan.cpp packs
+// (1 KiB per wave-instruction).
 //
 // D = W(32 cout x K) * X(K x 32 voxels): the accumulator keeps the voxel on the
-// lane and 4-channel runs in registers; the epilogue (bias, LeakyReLU, convert)
-// goes through LDS so every global store is a whole 16-byte piece of
-// consecutive voxel records.
+// lane and 4-channel runs in registers; the epilogue (LeakyReLU, convert; the
+// folded bias is the accumulators' initial value) goes through LDS so every
+// global store instruction writes 32 whole voxel records of one chunk plane.
 //
 // f32 uses v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 4 per chunk-tap),
 // bf16/f16 use v_mfma_f32_32x32x16_{bf16,f16} (one per chunk-tap).
 //
 // Two kernels share this scheme:
-//   conv3x3x3_zcol  32-cout slices (53 % of the FLOPs): wave = columns of the
+//   conv3x3x3_zpipe 32-cout slices (53 % of the FLOPs): wave = a column of the
 //                   tile, one LDS read feeds the three dz taps, the chunk's
-//                   weights are shared through LDS;
+//                   weights are shared through LDS, operand reads run a fixed
+//                   distance ahead of the MFMAs;
 //   conv3x3x3_t14   wider slices and the small pyramid levels: weights stream
 //                   from L2 through a register ring.
 // Both prefetch the next chunk global -> VGPR under the current chunk's MFMAs.
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
     const int wn = wave % WAVES_N;
     const int half = lane >> 5;
     // 16-wide rows: second row of a 32-voxel group in rotated x order, x = (i - HX)
-    // mod 16, so its lanes use the bank slots the first row leaves free (see zcol)
+    // mod 16, so its lanes use the bank slots the first row leaves free (see zpipe)
     const int r = (TX == 16 && (lane & 16)) ? 16 + (((lane & 15) - HX) & 15) : (lane & 31);
 
     int bid;
@@ -167,17 +173,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
         base[mt] = (z * HY + y) * HX + x + half * HV;
     }
 
+    // staging piece i = tid + it * NTHREADS is 16-byte group i & 1 of halo voxel
+    // i >> 1: consecutive lanes read consecutive bytes of a halo row of the chunk plane
     const size_t patch_vox = (size_t)a.d * a.h * a.w;
-    int vidx[NITEMS];
+    unsigned voffs[NITEMS];
 #pragma unroll
     for (int it = 0; it < NITEMS; ++it) {
         const int i = tid + it * NTHREADS;
-        const int hv = i >= HV ? i - HV : i;
+        const int hv = i >> 1;
         const int hz = hv / (HY * HX), hy = (hv / HX) % HY, hx = hv % HX;
         const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
         const bool ok = i < 2 * HV && (unsigned)gz < (unsigned)a.d &&
                         (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
-        vidx[it] = ok ? (gz * a.h + gy) * a.w + gx : -1;
+        voffs[it] = ok ? (unsigned)((gz * a.h + gy) * a.w + gx) * 32u + (i & 1) * 16u : kOutOfRange;
     }
 
     // accumulators start from the folded bias: register 4q+k of a lane is channel
@@ -206,22 +214,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
         } else {
             src = static_cast<const char*>(a.src_b); cs = a.cb; ch0 = c * KC - a.ca;
         }
-        const unsigned rowb = cs * ES;  // bytes of one voxel record of this source
-        const __amdgpu_buffer_rsrc_t rsrc =
-            make_rsrc(src + (size_t)nb * patch_vox * rowb, patch_vox * rowb);
+        const size_t patchb = patch_vox * cs * ES;  // bytes of one patch of this source
+        const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(src + (size_t)nb * patchb, patchb);
+        const unsigned cbase = (unsigned)(ch0 / KC) * (unsigned)patch_vox * 32u;  // chunk plane
 #pragma unroll
-        for (int it = 0; it < NITEMS; ++it) {
-            const int i = tid + it * NTHREADS;
-            const unsigned voff = vidx[it] >= 0 ? (unsigned)vidx[it] * rowb + (i >= HV ? 16u : 0u)
-                                                : kOutOfRange;
-            stg[it] = buf_load16(rsrc, voff, ch0 * ES);
-        }
+        for (int it = 0; it < NITEMS; ++it) stg[it] = buf_load16(rsrc, voffs[it], cbase);
     };
     auto stage_store = [&]() {
 #pragma unroll
         for (int it = 0; it < NITEMS; ++it) {
             const int i = tid + it * NTHREADS;
-            if (i < 2 * HV) lds[i] = stg[it];
+            if (i < 2 * HV) lds[(i & 1) * HV + (i >> 1)] = stg[it];
         }
     };
 
@@ -293,21 +296,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        constexpr int PPV = RECB / 16;           // 16-byte pieces per voxel slice
-        constexpr int ROUNDS = 32 * PPV / 64;
+        // one store instruction = one chunk plane's 32 voxel records (32 B each)
+        constexpr int NPL = RECB / 32;           // chunk planes of this wave's output slice
+        const int vv = lane >> 1, sub = lane & 1;
+        const int m = (wm * MT + mt) * 32 + vv;
+        const int z = m / (TY * TX), y = (m / TX) % TY, x = m % TX;
+        const int gz = z0 + z, gy = y0 + y, gx = x0 + x;
+        const bool ok = m < TILE_VOX && gz < a.d && gy < a.h && gx < a.w;
+        const size_t vox = ((size_t)gz * a.h + gy) * a.w + gx;
+        char* const dplane = static_cast<char*>(a.dst) +
+                             ((size_t)nb * (a.cout / KC) + ntile0 * (32 / KC)) * patch_vox * 32;
 #pragma unroll
-        for (int k = 0; k < ROUNDS; ++k) {
-            const int p = k * 64 + lane;
-            const int vv = p / PPV, part = p % PPV;
-            const int m = (wm * MT + mt) * 32 + vv;
-            const int z = m / (TY * TX), y = (m / TX) % TY, x = m % TX;
-            const int gz = z0 + z, gy = y0 + y, gx = x0 + x;
-            const uint4 val = *reinterpret_cast<const uint4*>(wl + vv * RECP + part * 16);
-            if (m < TILE_VOX && gz < a.d && gy < a.h && gx < a.w) {
-                const size_t vox = (((size_t)nb * a.d + gz) * a.h + gy) * a.w + gx;
-                *reinterpret_cast<uint4*>(static_cast<char*>(a.dst) +
-                                          (vox * a.cout + ntile0 * 32) * ES + part * 16) = val;
-            }
+        for (int ck = 0; ck < NPL; ++ck) {
+            const uint4 val = *reinterpret_cast<const uint4*>(wl + vv * RECP + (ck * 2 + sub) * 16);
+            if (ok)
+                *reinterpret_cast<uint4*>(dplane + ((size_t)ck * patch_vox + vox) * 32 + sub * 16) = val;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -315,62 +318,74 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
 }
 
 // Phase stamps for tools/conv_trace.hip (compiled out of the library).
+#ifndef EXASPIM_ABLATE
+#define EXASPIM_ABLATE 0   // tools only: 1 = no prefetch loads, 2 = no output stores, 4 = no LDS staging writes
+#endif
 #ifdef EXASPIM_TRACE
 #define EXA_TRACE(ev)                                                                          \
     do {                                                                                       \
         if (a.trace && lane == 0)                                                              \
-            a.trace[((size_t)blockIdx.x * NWAVES + wave) * 16 + (ev)] = __builtin_readcyclecounter(); \
+            a.trace[trace_rec + (ev)] = __builtin_readcyclecounter();                          \
     } while (0)
 #else
 #define EXA_TRACE(ev) do { } while (0)
 #endif
 
-// ---- conv3x3x3_zcol: z-column tiles ---------------------------------------------------
-// As v3, but a wave owns COLUMNS of the tile: YXW groups of 32 (y, x) positions
-// times all TZ planes (MT = TZ * YXW accumulators). For a fixed in-plane tap
-// (dy, dx) the operand fragment of input plane zin is the B operand of up to
-// three MFMAs (dz = 0, 1, 2 -> output planes zin, zin-1, zin-2), so the N = 32
-// GEMM needs (TZ + 2) LDS reads per 3 * TZ MFMAs instead of one read per MFMA.
-// Halo rows are padded to HXP = TX (mod 16) 16-byte slots so that the two
-// half-rows of a 32-voxel group never share a bank (no LDS conflicts for 16-
-// wide rows); padding slots are never written or read.
-// With WLDS the chunk's 27 weight fragments are staged in LDS as well (prefetched
-// global -> VGPR with the halo, one copy per workgroup instead of one L2 read per
-// wave): with 4 x 32-voxel tiles per wave the per-wave weight stream would
-// otherwise be 3x the activation traffic.
-template <typename Tag, int TZ, int TY, int TX, int WAVES_M, int WAVES_N, int YXW, int NT, int MINW, int PDG, bool WLDS, bool PADX = true, int HEAD = 0>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_zcol(
+// ---- conv3x3x3_zpipe: z-column tiles for the 32-cout slices ----------------------------
+// A wave owns one 32-voxel (y, x) group of the tile times all TZ planes (TZ
+// accumulators). For a fixed in-plane tap g = (dy, dx) the operand fragment of
+// input plane zin is the B operand of up to three MFMAs (dz = 0, 1, 2 -> output
+// planes zin, zin-1, zin-2): (TZ + 2) LDS reads per 3 * TZ MFMAs. The chunk's 27
+// weight fragments are staged in LDS too (one copy per workgroup instead of one L2
+// read per wave).
+//
+// Shaped by two measurements (tools/conv_trace.hip): a workgroup spends ~45 % of
+// its life outside the tap loops, so most of the time a SIMD has ONE wave feeding
+// its matrix pipe, and a wave whose operand reads sit right before the MFMAs that
+// use them reaches only ~70 % alone. Hence
+//  * the tap loop is one flat sequence of 9 * (TZ + 2) steps (g, zin); the operand
+//    fragment of step s + D is read from LDS before the MFMAs of step s into a ring
+//    of D + 1 registers, the next tap's three weight fragments are read one tap
+//    ahead, and a scheduling fence per step pins that order, so LDS latency hides
+//    under the wave's own MFMAs;
+//  * the next chunk's global loads are dealt one per step;
+//  * staging maps (column, 16-byte group) pairs to lanes, so with the blocked
+//    layout a load instruction covers whole halo rows of contiguous bytes (the
+//    texture addresser works per 64-byte segment: 16 cycles per instruction
+//    instead of 64 with one voxel record per lane).
+template <typename Tag, int TZ, int TY, int TX, int MINW, int D, int HEAD = 0>
+__global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
     ConvArgs a, int tiles_z, int tiles_y, int tiles_x) {
     constexpr int G = Tag::kG;
     constexpr int KC = 2 * G;
     constexpr int ES = 16 / G;
     constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
-    constexpr int HXP = (TX == 32 || !PADX) ? HX : (HX + 15) / 16 * 16 + (TX % 16);  // row stride (slots)
-    constexpr int HVP = HZ * HY * HXP;     // slots per channel group
-    constexpr int NWAVES = WAVES_M * WAVES_N;
+    constexpr int HXP = HX;                // row stride (slots)
+    constexpr int PLANE = HY * HXP;        // slots per halo plane
+    constexpr int HVP = HZ * PLANE;        // slots per channel group
+    constexpr int NWAVES = TY * TX / 32;
     constexpr int NTHREADS = NWAVES * 64;
-    constexpr int YXT = TY * TX / 32;      // 32-voxel (y, x) groups per plane
-    constexpr int MT = TZ * YXW;
-    constexpr int NCOL = HY * HX;          // (y, x) columns of the halo block
-    constexpr int NITEMS = 2 * HZ;         // staging pieces per thread: one column, 2 groups x HZ planes
-    constexpr int RECB = NT * 32 * ES;
-    constexpr int RECP = RECB + 16;  // padded LDS stride of the output transposition
+    constexpr int NPAIR = 2 * HY * HX;     // (column, group) pairs of the halo block
+    constexpr int REM = NPAIR > NTHREADS ? NPAIR - NTHREADS : 0;
+    constexpr int SEC = (REM * HZ + NTHREADS - 1) / NTHREADS;
+    constexpr int NITEMS = HZ + SEC;       // halo pieces per thread
+    constexpr int RECB = 32 * ES;
+    constexpr int RECP = RECB + 16;        // padded LDS stride of the output transposition
     constexpr int EPI_UNITS = NWAVES * 32 * RECP / 16;
-    constexpr int WUNITS = WLDS ? 27 * NT * 64 : 0;           // weight fragments in LDS
+    constexpr int WUNITS = 27 * 64;        // the chunk's weight fragments in LDS
     constexpr int WITEMS = (WUNITS + NTHREADS - 1) / NTHREADS;
     constexpr int XUNITS = 2 * HVP > EPI_UNITS ? 2 * HVP : EPI_UNITS;
     constexpr int LDS_UNITS = XUNITS + WUNITS;
-    static_assert(TY * TX % 32 == 0 && YXT == WAVES_M * YXW, "plane not covered by the waves");
-    static_assert(!WLDS || WAVES_N == 1, "LDS weights assume one cout slice per workgroup");
-    static_assert(NCOL <= NTHREADS, "one halo column per thread");
+    constexpr int NS = 9 * HZ;             // steps per chunk
+    constexpr int R = D + 1;               // operand ring
+    static_assert(TY * TX % 32 == 0 && NPAIR <= 2 * NTHREADS, "tile shape");
+    static_assert(NITEMS + WITEMS <= NS, "one staged piece per step");
 
     __shared__ __attribute__((aligned(16))) uint4 lds[LDS_UNITS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WAVES_N;
-    const int wn = wave % WAVES_N;
     const int half = lane >> 5;
     // Voxel of the 32-group this lane works on. With 16-wide rows the group is two
     // rows whose LDS slots differ by HXP; taking the second row's x in rotated
@@ -378,64 +393,95 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_zcol(
     // complement of what its ds_read_b128 lane group already uses: no conflicts.
     const int r = (TX == 16 && (lane & 16)) ? 16 + (((lane & 15) - HXP) & 15) : (lane & 31);
 
-    int bid;
+    // Tiles of this workgroup. The tile list is cut into 8 contiguous ranges, one per
+    // XCD (workgroups are dealt round-robin to the XCDs, so blockIdx.x & 7 is the XCD);
+    // the workgroups of an XCD walk their range together, slot by slot, so tiles that
+    // share halo planes are resident in the same L2 at the same time. With as many
+    // workgroups as tiles this is the plain one-tile-per-workgroup order.
+    const int total = tiles_z * tiles_y * tiles_x * a.n;
+    int t_first, t_count, t_step;
     {
-        const int nblk = gridDim.x, q = nblk >> 3, rem = nblk & 7;
+        const int q = total >> 3, rem = total & 7;
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
+        t_first = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
+        t_count = q + (xcd < rem ? 1 : 0) - slot;        // tiles left from t_first on
+        t_step = (gridDim.x + 7 - xcd) >> 3;             // workgroups on this XCD
     }
-    const int tx = bid % tiles_x; bid /= tiles_x;
-    const int ty = bid % tiles_y; bid /= tiles_y;
-    const int tz = bid % tiles_z; bid /= tiles_z;
-    const int nb = bid;
-    const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
-
+    if (t_count <= 0) return;
     const int ntiles = a.cout >> 5;
-    const int ntile0 = (blockIdx.y * WAVES_N + wn) * NT;
+    const int ntile0 = blockIdx.y;
 
-    // slot of this lane's voxel in plane 0 for each of the wave's (y, x) groups
-    int col[YXW];
-#pragma unroll
-    for (int j = 0; j < YXW; ++j) {
-        const int p = (wm * YXW + j) * 32 + r;  // position inside the plane
-        col[j] = (p / TX) * HXP + (p % TX) + half * HVP;
-    }
+    struct Tile {
+        int z0, y0, x0, nb;
+    };
+    auto tile_at = [&](int id) {
+        Tile t;
+        t.x0 = (id % tiles_x) * TX; id /= tiles_x;
+        t.y0 = (id % tiles_y) * TY; id /= tiles_y;
+        t.z0 = (id % tiles_z) * TZ; id /= tiles_z;
+        t.nb = id;
+        return t;
+    };
 
-    // Column staging: thread t < NCOL owns halo column (hy, hx) = (t / HX, t % HX)
-    // and moves its 2 x HZ pieces. All pieces of a thread share ONE vector offset
-    // (the column inside a plane); plane, channel group and chunk go into the
-    // scalar offset of the buffer load, so staging costs no per-piece VALU work.
-    const size_t patch_vox = (size_t)a.d * a.h * a.w;
+    const int pos = wave * 32 + r;  // this lane's position inside the plane
+    const int col = (pos / TX) * HXP + (pos % TX) + half * HVP;
+
+    // ---- staging map ----------------------------------------------------------
+    // primary: thread t < NPAIR moves pair t = (column t / 2, group t & 1), all HZ
+    // planes (one vector offset; plane and chunk ride in the scalar offset).
+    // secondary: the REM pairs beyond NTHREADS, piece q = t + k * NTHREADS is
+    // plane q / REM of pair NTHREADS + q % REM (own vector offset each).
+    // LDS slots do not depend on the tile; the global offsets are set per tile.
     const int plane_vox = a.h * a.w;
-    const bool colok = tid < NCOL;
-    const int chy = tid / HX, chx = tid % HX;
-    const int cgy = y0 + chy - 1, cgx = x0 + chx - 1;
-    const bool col_in = colok && (unsigned)cgy < (unsigned)a.h && (unsigned)cgx < (unsigned)a.w;
-    const int colvox = cgy * a.w + cgx;        // voxel of the column inside a plane
-    const int colslot = chy * HXP + chx;       // its LDS slot inside a plane
+    const size_t patch_vox = (size_t)a.d * plane_vox;
+    const bool p_ok = tid < NPAIR;
+    const int p_hy = (tid >> 1) / HX, p_hx = (tid >> 1) % HX, p_kg = tid & 1;
+    const int p_slot = p_kg * HVP + p_hy * HXP + p_hx;
+    unsigned p_voff;      // byte offset inside a z-plane of a chunk plane (or out of range)
+    unsigned s_voff[SEC > 0 ? SEC : 1];
+    int s_slot[SEC > 0 ? SEC : 1];
+#pragma unroll
+    for (int k = 0; k < SEC; ++k) {
+        const int q = tid + k * NTHREADS;
+        const int pr = NTHREADS + q % REM, hz = q / REM;
+        const int c = pr >> 1, kg = pr & 1;
+        s_slot[k] = q < REM * HZ ? kg * HVP + hz * PLANE + (c / HX) * HXP + c % HX : -1;
+    }
+    auto set_offsets = [&](const Tile& t) {
+        {
+            const int gy = t.y0 + p_hy - 1, gx = t.x0 + p_hx - 1;
+            const bool in = p_ok && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
+            p_voff = in ? (unsigned)(gy * a.w + gx) * 32u + p_kg * 16u : kOutOfRange;
+        }
+#pragma unroll
+        for (int k = 0; k < SEC; ++k) {
+            const int q = tid + k * NTHREADS;
+            const int pr = NTHREADS + q % REM, hz = q / REM;
+            const int c = pr >> 1, kg = pr & 1;
+            const int gz = t.z0 + hz - 1, gy = t.y0 + c / HX - 1, gx = t.x0 + c % HX - 1;
+            const bool in = q < REM * HZ && (unsigned)gz < (unsigned)a.d &&
+                            (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
+            s_voff[k] = in ? (unsigned)((gz * a.h + gy) * a.w + gx) * 32u + kg * 16u : kOutOfRange;
+        }
+    };
     // weight fragments: piece i = tid + it * NTHREADS is element (i & 63) of tap i >> 6
     const unsigned wvoff = (((tid >> 6) * ntiles) * 64 + (tid & 63)) * 16u;
 
-    // accumulators start from the folded bias: register 4q+k of a lane is channel
-    // 8q + 4*half + k of its slice (no bias pass in the epilogue)
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 b = *reinterpret_cast<const float4*>(a.bias + (ntile0 + nt) * 32 + 8 * q + 4 * half);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                acc[mt][nt][4 * q + 0] = b.x; acc[mt][nt][4 * q + 1] = b.y;
-                acc[mt][nt][4 * q + 2] = b.z; acc[mt][nt][4 * q + 3] = b.w;
-            }
-        }
+    // the slice's folded bias, kept in LDS: every tile's accumulators start from it
+    __shared__ __attribute__((aligned(16))) float bias_s[32];
+    if (tid < 32) bias_s[tid] = a.bias[ntile0 * 32 + tid];
 
     const int nchunks = (a.ca + a.cb) / KC;
     uint4 stg[NITEMS + WITEMS];  // halo pieces, then weight fragments
     uint4* const wlds = lds + XUNITS;
+    const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(a.weights, (size_t)nchunks * 27 * ntiles * 1024);
 
-    auto stage_load = [&](int c) {
+    // where chunk c of patch nb lives: descriptor of the patch of its source, offset of its plane
+    struct ChunkSrc {
+        __amdgpu_buffer_rsrc_t rsrc;
+        unsigned cbase;
+    };
+    auto chunk_src = [&](int c, int nb) {
         const char* src;
         int cs, ch0;
         if (c * KC < a.ca) {
@@ -443,234 +489,269 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_zcol(
         } else {
             src = static_cast<const char*>(a.src_b); cs = a.cb; ch0 = c * KC - a.ca;
         }
-        const unsigned rowb = cs * ES;  // bytes of one voxel record of this source
-        const __amdgpu_buffer_rsrc_t rsrc =
-            make_rsrc(src + (size_t)nb * patch_vox * rowb, patch_vox * rowb);
-        const unsigned voff = col_in ? (unsigned)colvox * rowb : kOutOfRange;
-        const unsigned planeb = (unsigned)plane_vox * rowb;
-#pragma unroll
-        for (int hz = 0; hz < HZ; ++hz) {
-            const int gz = z0 + hz - 1;           // wave-uniform
-            const bool zin = (unsigned)gz < (unsigned)a.d;
-#pragma unroll
-            for (int kg = 0; kg < 2; ++kg)
-                stg[kg * HZ + hz] = zin ? buf_load16(rsrc, voff, (unsigned)gz * planeb + ch0 * ES + kg * 16)
-                                        : make_uint4(0, 0, 0, 0);
-        }
-        if (WLDS) {
-            const __amdgpu_buffer_rsrc_t wrsrc =
-                make_rsrc(a.weights, (size_t)nchunks * 27 * ntiles * 1024);
-#pragma unroll
-            for (int it = 0; it < WITEMS; ++it) {
-                // taps it * NWAVES + wave; the last round covers taps < 27 only
-                const bool live = it * NWAVES + wave < 27;
-                stg[NITEMS + it] = live ? buf_load16(wrsrc, wvoff,
-                                                     ((c * 27 + it * NWAVES) * ntiles + ntile0) * 1024)
-                                        : make_uint4(0, 0, 0, 0);
+        const size_t patchb = patch_vox * cs * ES;  // bytes of one patch of this source
+        return ChunkSrc{make_rsrc(src + (size_t)nb * patchb, patchb),
+                        (unsigned)(ch0 / KC) * (unsigned)patch_vox * 32u};
+    };
+    // piece i of chunk c of the tile whose first plane is z0: global -> stg[i]
+    auto load_piece = [&](const ChunkSrc& cs, int c, int z0, int i) {
+        if (i < NITEMS) {
+            if (i < HZ) {
+                const int gz = z0 + i - 1;  // wave-uniform
+                stg[i] = (unsigned)gz < (unsigned)a.d
+                             ? buf_load16(cs.rsrc, p_voff, cs.cbase + (unsigned)gz * plane_vox * 32u)
+                             : make_uint4(0, 0, 0, 0);
+            } else {
+                stg[i] = buf_load16(cs.rsrc, s_voff[i - HZ], cs.cbase);
             }
+        } else {
+            const int it = i - NITEMS;
+            // taps it * NWAVES + wave; the last round covers taps < 27 only
+            stg[i] = it * NWAVES + wave < 27
+                         ? buf_load16(wrsrc, wvoff, ((c * 27 + it * NWAVES) * ntiles + ntile0) * 1024)
+                         : make_uint4(0, 0, 0, 0);
         }
     };
     auto stage_store = [&]() {
-        if (colok) {
+        if ((EXASPIM_ABLATE & 4) && stg[0].x != 0x12345u) return;
+        if (p_ok) {
 #pragma unroll
-            for (int kg = 0; kg < 2; ++kg)
-#pragma unroll
-                for (int hz = 0; hz < HZ; ++hz)
-                    lds[kg * HVP + hz * HY * HXP + colslot] = stg[kg * HZ + hz];
+            for (int hz = 0; hz < HZ; ++hz) lds[p_slot + hz * PLANE] = stg[hz];
         }
-        if (WLDS) {
 #pragma unroll
-            for (int it = 0; it < WITEMS; ++it) {
-                const int i = tid + it * NTHREADS;
-                if (i < WUNITS) wlds[i] = stg[NITEMS + it];
-            }
+        for (int k = 0; k < SEC; ++k)
+            if (s_slot[k] >= 0) lds[s_slot[k]] = stg[HZ + k];
+#pragma unroll
+        for (int it = 0; it < WITEMS; ++it) {
+            const int i = tid + it * NTHREADS;
+            if (i < WUNITS) wlds[i] = stg[NITEMS + it];
         }
     };
 
-#ifdef EXASPIM_TRACE
-    if (a.trace && lane == 0)
-        a.trace[((size_t)blockIdx.x * NWAVES + wave) * 16 + 15] =
-            ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
-            (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
-#endif
-    EXA_TRACE(0);
-    stage_load(0);
-    EXA_TRACE(1);
-    stage_store();
-    __syncthreads();
-    EXA_TRACE(2);
-
-    for (int c = 0; c < nchunks; ++c) {
-        const uint4* wp = static_cast<const uint4*>(a.weights) +
-                          ((size_t)c * 27 * ntiles + ntile0) * 64 + lane;
-        // weight ring over in-plane taps g = dy * 3 + dx: three fragments (dz) each
-        uint4 wring[PDG + 1][3][NT];
-        if (!WLDS)
+    int tile_id = t_first;
+    Tile cur = tile_at(tile_id);
+    set_offsets(cur);
+    {
+        const ChunkSrc cs0 = chunk_src(0, cur.nb);
 #pragma unroll
-        for (int g = 0; g < PDG; ++g)
-#pragma unroll
-            for (int dz = 0; dz < 3; ++dz)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    wring[g][dz][nt] = wp[((size_t)(dz * 9 + g) * ntiles + nt) * 64];
-
-        const bool more = c + 1 < nchunks;
-#pragma unroll
-        for (int g = 0; g < 9; ++g) {
-            if (WLDS) {
-#pragma unroll
-                for (int dz = 0; dz < 3; ++dz)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        wring[g % (PDG + 1)][dz][nt] = wlds[((dz * 9 + g) * NT + nt) * 64 + lane];
-            } else if (g + PDG < 9) {
-#pragma unroll
-                for (int dz = 0; dz < 3; ++dz)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        wring[(g + PDG) % (PDG + 1)][dz][nt] =
-                            wp[((size_t)(dz * 9 + g + PDG) * ntiles + nt) * 64];
-            }
-            if (g == (WLDS ? 0 : 9 - PDG - 1) && more) stage_load(c + 1);
-            const int goff = (g / 3) * HXP + g % 3;
-#pragma unroll
-            for (int j = 0; j < YXW; ++j) {
-                uint4 xf[HZ];
-#pragma unroll
-                for (int zin = 0; zin < HZ; ++zin) xf[zin] = lds[col[j] + zin * HY * HXP + goff];
-#pragma unroll
-                for (int zin = 0; zin < HZ; ++zin)
-#pragma unroll
-                    for (int dz = 0; dz < 3; ++dz) {
-                        const int z = zin - dz;
-                        if (z >= 0 && z < TZ) {
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
-                                mma<Tag>(acc[j * TZ + z][nt], wring[g % (PDG + 1)][dz][nt], xf[zin]);
-                        }
-                    }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (c < 4) EXA_TRACE(3 + 3 * c);
-        __syncthreads();
-        if (c < 4) EXA_TRACE(4 + 3 * c);
-        if (more) {
-            stage_store();
-            __syncthreads();
-            if (c < 3) EXA_TRACE(5 + 3 * c);
-        }
+        for (int i = 0; i < NITEMS + WITEMS; ++i) load_piece(cs0, 0, cur.z0, i);
     }
+    stage_store();
 
-    if (HEAD > 0) {
-        // ---- fused head: OutConv 1x1x1 (+ sigmoid) on the accumulators -----------
-        // lane (voxel r, half h) holds channels 8q + 4h + j of its voxel: a 16-term
-        // partial dot product per output, completed by the other half-wave.
-        static_assert(HEAD == 0 || NT == 1, "the fused head needs the whole 32-channel record");
-        float hw[HEAD > 0 ? HEAD : 1][16];
+    for (;;) {
+#ifdef EXASPIM_TRACE
+        const size_t trace_rec = ((size_t)tile_id * NWAVES + wave) * 16;
+        if (a.trace && lane == 0)
+            a.trace[trace_rec + 15] =
+                ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
+        EXA_TRACE(0);
+        EXA_TRACE(1);
+        __syncthreads();   // this tile's first chunk (and, the first time, the bias) is in LDS
+        // register 4q+k of a lane is channel 8q + 4*half + k of the slice
+        f32x16 acc[TZ];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            const float4 b = *reinterpret_cast<const float4*>(bias_s + 8 * q + 4 * half);
 #pragma unroll
-            for (int o = 0; o < HEAD; ++o) {
-                const float4 t = *reinterpret_cast<const float4*>(a.head_w + o * 32 + 8 * q + 4 * half);
-                hw[o][4 * q + 0] = t.x; hw[o][4 * q + 1] = t.y;
-                hw[o][4 * q + 2] = t.z; hw[o][4 * q + 3] = t.w;
+            for (int mt = 0; mt < TZ; ++mt) {
+                acc[mt][4 * q + 0] = b.x; acc[mt][4 * q + 1] = b.y;
+                acc[mt][4 * q + 2] = b.z; acc[mt][4 * q + 3] = b.w;
             }
         }
-        float hb[HEAD > 0 ? HEAD : 1];
+        EXA_TRACE(2);
+
+        // During the last chunk the first chunk of the workgroup's NEXT tile is
+        // prefetched, so only the first tile of a workgroup pays the global latency.
+        t_count -= t_step;
+        const bool has_next = t_count > 0;
+        Tile nxt = cur;
+        for (int c = 0; c < nchunks; ++c) {
+            const bool more = c + 1 < nchunks;
+            const bool pre = more || has_next;
+            if (!more && has_next) {
+                nxt = tile_at(tile_id + t_step);
+                set_offsets(nxt);   // every load of the current tile has been issued
+            }
+            const ChunkSrc csn = chunk_src(more ? c + 1 : 0, more ? cur.nb : nxt.nb);
+            const int cn = more ? c + 1 : 0, zn = more ? cur.z0 : nxt.z0;
+            uint4 xr[R];       // operand ring: fragment of step s lives in xr[s % R]
+            // weight fragments (dz) of tap g: fragment dz is used in steps zin = dz ..
+            // dz + TZ - 1 of its tap, so the next tap's fragment takes over the register
+            // as soon as that window closes (two steps before its own window opens)
+            uint4 wb[3];
 #pragma unroll
-        for (int o = 0; o < HEAD; ++o) hb[o] = a.head_b[o];
-        const size_t plane = (size_t)a.h * a.w;
+            for (int dz = 0; dz < 3; ++dz) wb[dz] = wlds[(dz * 9) * 64 + lane];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int j = mt / TZ, z = mt % TZ;
-            float part[HEAD > 0 ? HEAD : 1];
+            for (int s = 0; s < D; ++s)
+                xr[s % R] = lds[col + (s % HZ) * PLANE + ((s / HZ) / 3) * HXP + (s / HZ) % 3];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int o = 0; o < HEAD; ++o) part[o] = 0.f;
+            for (int s = 0; s < NS; ++s) {
+                const int g = s / HZ, zin = s % HZ;
+                if (s + D < NS) {
+                    const int g2 = (s + D) / HZ, z2 = (s + D) % HZ;
+                    xr[(s + D) % R] = lds[col + z2 * PLANE + (g2 / 3) * HXP + g2 % 3];
+                }
+                if (g + 1 < 9 && zin >= TZ) wb[zin - TZ] = wlds[((zin - TZ) * 9 + g + 1) * 64 + lane];
+                if (g > 0 && zin == 0) wb[2] = wlds[(2 * 9 + g) * 64 + lane];
+                if (!(EXASPIM_ABLATE & 1) && pre && s < NITEMS + WITEMS) load_piece(csn, cn, zn, s);
+#pragma unroll
+                for (int dz = 0; dz < 3; ++dz) {
+                    const int z = zin - dz;
+                    if (z >= 0 && z < TZ) mma<Tag>(acc[z], wb[dz], xr[s % R]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (c < 4) EXA_TRACE(3 + 3 * c);
+            __syncthreads();   // every wave is done reading this chunk's image
+            if (c < 4) EXA_TRACE(4 + 3 * c);
+            if (more) {
+                stage_store();
+                __syncthreads();
+                if (c < 3) EXA_TRACE(5 + 3 * c);
+            }
+        }
+
+        if (HEAD > 0) {
+            // ---- fused head: OutConv 1x1x1 (+ sigmoid) on the accumulators -----------
+            // lane (voxel r, half h) holds channels 8q + 4h + j of its voxel: a 16-term
+            // partial dot product per output, completed by the other half-wave.
+            float hw[HEAD > 0 ? HEAD : 1][16];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float v = acc[mt][0][4 * q + k];
-                    v = fmaxf(v, v * a.slope);
-#pragma unroll
-                    for (int o = 0; o < HEAD; ++o) part[o] = fmaf(v, hw[o][4 * q + k], part[o]);
+                for (int o = 0; o < HEAD; ++o) {
+                    const float4 t = *reinterpret_cast<const float4*>(a.head_w + o * 32 + 8 * q + 4 * half);
+                    hw[o][4 * q + 0] = t.x; hw[o][4 * q + 1] = t.y;
+                    hw[o][4 * q + 2] = t.z; hw[o][4 * q + 3] = t.w;
                 }
             }
-            const int pos = (wm * YXW + j) * 32 + r;
-            const int gz = z0 + z, gy = y0 + pos / TX, gx = x0 + pos % TX;
-            const bool ok = gz < a.d && gy < a.h && gx < a.w;
+            float hb[HEAD > 0 ? HEAD : 1];
 #pragma unroll
-            for (int o = 0; o < HEAD; ++o) {
-                float t = part[o] + __shfl_xor(part[o], 32) + hb[o];
-                if (a.head_sigmoid) t = 1.f / (1.f + expf(-t));
-                // outputs are dealt to the two half-waves so both store
-                if (ok && (o & 1) == half)
-                    a.head_out[(((size_t)nb * HEAD + o) * a.d + gz) * plane + (size_t)gy * a.w + gx] = t;
+            for (int o = 0; o < HEAD; ++o) hb[o] = a.head_b[o];
+            const size_t plane = (size_t)a.h * a.w;
+            const int gy = cur.y0 + pos / TX, gx = cur.x0 + pos % TX;
+#pragma unroll
+            for (int z = 0; z < TZ; ++z) {
+                float part[HEAD > 0 ? HEAD : 1];
+#pragma unroll
+                for (int o = 0; o < HEAD; ++o) part[o] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    float v = acc[z][k];
+                    v = fmaxf(v, v * a.slope);
+#pragma unroll
+                    for (int o = 0; o < HEAD; ++o) part[o] = fmaf(v, hw[o][k], part[o]);
+                }
+                const int gz = cur.z0 + z;
+                const bool ok = gz < a.d && gy < a.h && gx < a.w;
+#pragma unroll
+                for (int o = 0; o < HEAD; ++o) {
+                    float t = part[o] + __shfl_xor(part[o], 32) + hb[o];
+                    if (a.head_sigmoid) t = 1.f / (1.f + expf(-t));
+                    // outputs are dealt to the two half-waves so both store
+                    if (ok && (o & 1) == half)
+                        a.head_out[(((size_t)cur.nb * HEAD + o) * a.d + gz) * plane + (size_t)gy * a.w + gx] = t;
+                }
+            }
+        } else {
+            // ---- epilogue: LeakyReLU, transposed through LDS ----------------------
+            // One store instruction writes one chunk plane's 32 voxel records (32 B
+            // each): two runs of 512 contiguous bytes when the tile row is 16 voxels.
+            // The (dead) halo and weight image gives every wave room for TB planes at
+            // once, so the LDS round trips and the stores of a batch overlap.
+            constexpr int CPT = RECB / 32;                       // chunk planes of a 32-cout slice
+            constexpr int TB_MAX = LDS_UNITS * 16 / (NWAVES * 32 * RECP);
+            constexpr int TB = TB_MAX >= TZ ? TZ : (TB_MAX >= (TZ + 1) / 2 ? (TZ + 1) / 2 : 1);
+            char* wl = reinterpret_cast<char*>(lds) + wave * (TB * 32 * RECP);
+            char* const dplane = static_cast<char*>(a.dst) +
+                                 ((size_t)cur.nb * (a.cout / KC) + ntile0 * CPT) * patch_vox * 32;
+            const int vv = lane >> 1, sub = lane & 1;
+            const int po = wave * 32 + vv;
+            const int ogy = cur.y0 + po / TX, ogx = cur.x0 + po % TX;
+#pragma unroll
+            for (int zb = 0; zb < TZ; zb += TB) {
+#pragma unroll
+                for (int z = zb; z < zb + TB && z < TZ; ++z) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int cl = 8 * q + 4 * half;
+                        // LeakyReLU with 0 <= slope <= 1 is max(v, slope * v)
+                        float v0 = acc[z][4 * q + 0], v1 = acc[z][4 * q + 1];
+                        float v2 = acc[z][4 * q + 2], v3 = acc[z][4 * q + 3];
+                        v0 = fmaxf(v0, v0 * a.slope);
+                        v1 = fmaxf(v1, v1 * a.slope);
+                        v2 = fmaxf(v2, v2 * a.slope);
+                        v3 = fmaxf(v3, v3 * a.slope);
+                        store4<Tag>(wl + (z - zb) * (32 * RECP), (size_t)(r * RECP) / ES + cl, v0, v1, v2, v3);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int z = zb; z < zb + TB && z < TZ; ++z) {
+                    const int gz = cur.z0 + z;
+                    const bool ok = gz < a.d && ogy < a.h && ogx < a.w;
+                    const size_t vox = ((size_t)gz * a.h + ogy) * a.w + ogx;
+#pragma unroll
+                    for (int ck = 0; ck < CPT; ++ck) {
+                        const uint4 val = *reinterpret_cast<const uint4*>(
+                            wl + (z - zb) * (32 * RECP) + vv * RECP + (ck * 2 + sub) * 16);
+                        if (ok && (!(EXASPIM_ABLATE & 2) || val.x == 0x12345u))
+                            *reinterpret_cast<uint4*>(dplane + ((size_t)ck * patch_vox + vox) * 32 + sub * 16) = val;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
         }
-        return;
+        EXA_TRACE(14);
+        if (!has_next) break;
+        if (HEAD == 0) __syncthreads();   // the transposition buffers are free again
+        stage_store();
+        tile_id += t_step;
+        cur = nxt;
     }
-
-    // ---- epilogue: bias + LeakyReLU, transposed through LDS ------------------
-    char* wl = reinterpret_cast<char*>(lds) + wave * (32 * RECP);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int j = mt / TZ, z = mt % TZ;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int cl = nt * 32 + 8 * q + 4 * half;
-                // LeakyReLU with 0 <= slope <= 1 is max(v, slope * v)
-                float v0 = acc[mt][nt][4 * q + 0], v1 = acc[mt][nt][4 * q + 1];
-                float v2 = acc[mt][nt][4 * q + 2], v3 = acc[mt][nt][4 * q + 3];
-                v0 = fmaxf(v0, v0 * a.slope);
-                v1 = fmaxf(v1, v1 * a.slope);
-                v2 = fmaxf(v2, v2 * a.slope);
-                v3 = fmaxf(v3, v3 * a.slope);
-                store4<Tag>(wl, (size_t)(r * RECP) / ES + cl, v0, v1, v2, v3);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        constexpr int PPV = RECB / 16;
-        constexpr int ROUNDS = 32 * PPV / 64;
-#pragma unroll
-        for (int k = 0; k < ROUNDS; ++k) {
-            const int p = k * 64 + lane;
-            const int vv = p / PPV, part = p % PPV;
-            const int pos = (wm * YXW + j) * 32 + vv;
-            const int gz = z0 + z, gy = y0 + pos / TX, gx = x0 + pos % TX;
-            const uint4 val = *reinterpret_cast<const uint4*>(wl + vv * RECP + part * 16);
-            if (gz < a.d && gy < a.h && gx < a.w) {
-                const size_t vox = (((size_t)nb * a.d + gz) * a.h + gy) * a.w + gx;
-                *reinterpret_cast<uint4*>(static_cast<char*>(a.dst) +
-                                          (vox * a.cout + ntile0 * 32) * ES + part * 16) = val;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    EXA_TRACE(14);
 }
 
-template <typename Tag, int TZ, int TY, int TX, int WAVES_M, int WAVES_N, int YXW, int NT, int MINW, int PDG, bool WLDS = false, bool PADX = true, int HEAD = 0>
-static int launch_zcol(const ConvArgs& a, hipStream_t stream) {
-    constexpr int NWG = WAVES_N * NT * 32;
-    if (a.cout % NWG != 0) {
-        set_error("conv: cout %d not a multiple of the %d-channel tile", a.cout, NWG);
-        return EXASPIM_E_INVALID;
+#ifdef EXASPIM_TRACE
+int g_variant = 0;   // tools/conv_trace.hip: 3/5/6 = operand prefetch distance, +10 = one tile per workgroup
+#endif
+
+// workgroup slots of the device for a kernel that runs MINW workgroups per CU
+static int resident_workgroups(int per_cu) {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        cus = n;
     }
+    return cus * per_cu;
+}
+
+template <typename Tag, int TZ, int TY, int TX, int MINW, int D, int HEAD = 0>
+static int launch_zpipe(const ConvArgs& a, hipStream_t stream) {
     const int tz = (a.d + TZ - 1) / TZ, ty = (a.h + TY - 1) / TY, tx = (a.w + TX - 1) / TX;
     const long long blocks = (long long)tz * ty * tx * a.n;
     if (blocks <= 0 || blocks > 0x7fffffffLL) {
         set_error("conv: grid of %lld blocks out of range", blocks);
         return EXASPIM_E_INVALID;
     }
-    dim3 grid((unsigned)blocks, a.cout / NWG);
-    conv3x3x3_zcol<Tag, TZ, TY, TX, WAVES_M, WAVES_N, YXW, NT, MINW, PDG, WLDS, PADX, HEAD>
-        <<<grid, WAVES_M * WAVES_N * 64, 0, stream>>>(a, tz, ty, tx);
+    // persistent workgroups: as many as the device holds at once (a multiple of the 8
+    // XCDs), each walking its share of the tile list with cross-tile prefetch
+    const int slices = a.cout / 32;
+    long long wgs = resident_workgroups(MINW) / slices / 8 * 8;
+    if (wgs < 8) wgs = 8;
+    if (wgs > blocks) wgs = blocks;
+#ifdef EXASPIM_TRACE
+    if (g_variant >= 10) wgs = blocks;
+#endif
+    dim3 grid((unsigned)wgs, slices);
+    conv3x3x3_zpipe<Tag, TZ, TY, TX, MINW, D, HEAD><<<grid, TY * TX * 2, 0, stream>>>(a, tz, ty, tx);
     EXA_CHECK_HIP(hipGetLastError());
     return EXASPIM_OK;
 }
@@ -699,17 +780,27 @@ static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
 }
 
 // 32-cout slice on z-column tiles of TZ planes, with or without the fused head
-template <typename Tag, int TZ>
-static int launch_zcol_head(const ConvArgs& a, hipStream_t stream) {
+// 32-cout slice on z-column tiles of TZ planes, with or without the fused head
+template <typename Tag, int TZ, int D>
+static int launch_zpipe_head(const ConvArgs& a, hipStream_t stream) {
     if (a.head_out && a.cout == 32) {
         switch (a.head_oc) {
-            case 1: return launch_zcol<Tag, TZ, 8, 16, 4, 1, 1, 1, 2, 1, true, false, 1>(a, stream);
-            case 2: return launch_zcol<Tag, TZ, 8, 16, 4, 1, 1, 1, 2, 1, true, false, 2>(a, stream);
-            case 3: return launch_zcol<Tag, TZ, 8, 16, 4, 1, 1, 1, 2, 1, true, false, 3>(a, stream);
-            case 4: return launch_zcol<Tag, TZ, 8, 16, 4, 1, 1, 1, 2, 1, true, false, 4>(a, stream);
+            case 1: return launch_zpipe<Tag, TZ, 8, 16, 2, D, 1>(a, stream);
+            case 2: return launch_zpipe<Tag, TZ, 8, 16, 2, D, 2>(a, stream);
+            case 3: return launch_zpipe<Tag, TZ, 8, 16, 2, D, 3>(a, stream);
+            case 4: return launch_zpipe<Tag, TZ, 8, 16, 2, D, 4>(a, stream);
         }
     }
-    return launch_zcol<Tag, TZ, 8, 16, 4, 1, 1, 1, 2, 1, true, false>(a, stream);
+    return launch_zpipe<Tag, TZ, 8, 16, 2, D>(a, stream);
+}
+
+template <typename Tag, int TZ>
+static int launch_zpipe_d(const ConvArgs& a, hipStream_t stream) {
+#ifdef EXASPIM_TRACE
+    if (g_variant % 10 == 3) return launch_zpipe_head<Tag, TZ, 3>(a, stream);
+    if (g_variant % 10 == 5) return launch_zpipe_head<Tag, TZ, 5>(a, stream);
+#endif
+    return launch_zpipe_head<Tag, TZ, 4>(a, stream);
 }
 
 template <typename Tag>
@@ -720,8 +811,8 @@ static int launch_typed(const ConvArgs& a, hipStream_t stream) {
         // 32-cout slices: z-column tiles with the chunk's weights shared through LDS
         if (a.cout % 64 != 0) {
             // 6-plane tiles when the depth divides (96, 48, 24): more dz reuse per LDS read
-            if (a.d % 6 == 0) return launch_zcol_head<Tag, 6>(a, stream);
-            return launch_zcol_head<Tag, 4>(a, stream);
+            if (a.d % 6 == 0) return launch_zpipe_d<Tag, 6>(a, stream);
+            return launch_zpipe_d<Tag, 4>(a, stream);
         }
         return launch_cfg<Tag, 4, 8, 16, 4, 1, 4, 2, 2>(a, stream);
     }

@@ -1,11 +1,13 @@
-// HBM-bound layers of the U-Net on channels-last activations:
+// The layers of the U-Net around the 3x3x3 convolutions, on the blocked
+// channels-last layout of conv3d.hip, (N, C / chunk, D, H, W, 32 B):
 //   conv_first : inc.0, Conv3d(1 -> C0, k3, p1) + folded BN + LeakyReLU
 //                (machine_learning/unet3d.py:64,143-145) from the float32 patch
 //   maxpool2   : nn.MaxPool3d(2)                          (unet3d.py:195)
 //   upsample2  : nn.Upsample(x2, trilinear, align_corners=True) (unet3d.py:248)
 //   head       : OutConv 1x1x1 (+ sigmoid of inference.py:158) -> NCDHW float32
 // Every thread moves 16-byte channel groups; consecutive lanes touch
-// consecutive addresses.
+// consecutive addresses. Max-pool and interpolation act per channel, so they see
+// the tensor as N * C / chunk independent volumes of 32-byte voxel records.
 
 #include "common.h"
 
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(
     constexpr int ES = 16 / G;
     constexpr int RECB = 32 * ES;           // bytes of one voxel's 32-channel slice
     constexpr int RECP = RECB + 16;         // padded LDS stride (2-way instead of 8-way conflicts)
-    constexpr int PPV = RECB / 16;
+    constexpr int CPT = RECB / 32;          // chunk planes of a 32-channel slice
     __shared__ __attribute__((aligned(16))) char tr[4 * 32 * RECP];
     char* wl = tr + wave * (32 * RECP);
 #pragma unroll
@@ -172,14 +174,18 @@ __global__ __launch_bounds__(256) void conv_first_kernel(
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // one store instruction = one chunk plane's 32 voxel records
+        const int vv = lane >> 1, sub = lane & 1;
+        const int v = v0 + mt * 32 + vv;
+        const int vc = v < nvox ? v : nvox - 1;
+        const int nb = vc / dhw, sp = vc - nb * dhw;
+        char* const dplane = static_cast<char*>(dst) +
+                             ((size_t)nb * (c0p * ES / 32) + blockIdx.y * CPT) * dhw * 32;
 #pragma unroll
-        for (int k = 0; k < 32 * PPV / 64; ++k) {
-            const int p = k * 64 + lane;
-            const int v = v0 + mt * 32 + p / PPV;
-            const uint4 val = *reinterpret_cast<const uint4*>(wl + (p / PPV) * RECP + (p % PPV) * 16);
+        for (int ck = 0; ck < CPT; ++ck) {
+            const uint4 val = *reinterpret_cast<const uint4*>(wl + vv * RECP + (ck * 2 + sub) * 16);
             if (v < nvox)
-                *reinterpret_cast<uint4*>(static_cast<char*>(dst) +
-                                          ((size_t)v * c0p + co_tile) * ES + (p % PPV) * 16) = val;
+                *reinterpret_cast<uint4*>(dplane + ((size_t)ck * dhw + sp) * 32 + sub * 16) = val;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -245,27 +251,31 @@ __global__ __launch_bounds__(256) void convt2_kernel(const uint4* __restrict__ s
             acc[ph][4 * q + 2] = b.z; acc[ph][4 * q + 3] = b.w;
         }
     }
-    const uint4* xrow = src + (size_t)vc * (cin / G) + half;   // 16-byte groups of this voxel
+    const int hw = h * w, dhw = d * hw;
+    const int nbc = vc / dhw, spc = vc - nbc * dhw;
+    // this lane's 16-byte group of the voxel's record in chunk plane 0; planes are dhw records apart
+    const uint4* xrow = src + ((size_t)nbc * nchunks * dhw + spc) * 2 + half;
     for (int c = 0; c < nchunks; ++c) {
-        const uint4 xf = xrow[2 * c];
+        const uint4 xf = xrow[(size_t)c * dhw * 2];
         const uint4* wp = wts + (((size_t)c * 8) * ntiles + ntile) * 64 + lane;
 #pragma unroll
         for (int ph = 0; ph < 8; ++ph) mma_ct<T>(acc[ph], wp[(size_t)ph * ntiles * 64], xf);
     }
     if (v >= nvox) return;
-    const int hw = h * w, dhw = d * hw;
-    const int nb = v / dhw, sp = v - nb * dhw;
+    const int nb = nbc, sp = spc;
     const int z = sp / hw, y = (sp - z * hw) / w, x = sp - z * hw - y * w;
     const int oh = 2 * h, ow = 2 * w;
+    const size_t odhw = (size_t)8 * dhw;
+    char* const oplane = static_cast<char*>(dst) + ((size_t)nb * (cout / KC) + ntile * (32 / KC)) * odhw * 32;
 #pragma unroll
     for (int ph = 0; ph < 8; ++ph) {
-        const size_t ovox = (((size_t)nb * 2 * d + 2 * z + (ph >> 2)) * oh + 2 * y + ((ph >> 1) & 1)) * ow +
+        const size_t ovox = ((size_t)(2 * z + (ph >> 2)) * oh + 2 * y + ((ph >> 1) & 1)) * ow +
                             2 * x + (ph & 1);
-        char* orec = static_cast<char*>(dst) + (ovox * cout + ntile * 32) * ES;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float o4[4] = {acc[ph][4 * q], acc[ph][4 * q + 1], acc[ph][4 * q + 2], acc[ph][4 * q + 3]};
-            char* out = orec + (8 * q + 4 * half) * ES;
+            const int byte = (8 * q + 4 * half) * ES;   // inside the 32-channel slice
+            char* out = oplane + ((size_t)(byte / 32) * odhw + ovox) * 32 + byte % 32;
             if (G == 4) {
                 *reinterpret_cast<float4*>(out) = make_float4(o4[0], o4[1], o4[2], o4[3]);
             } else {
@@ -373,13 +383,14 @@ __global__ __launch_bounds__(256) void head_kernel(const uint4* __restrict__ src
     if (sp >= nvox_per_patch) return;
     const unsigned nb = blockIdx.y;
     const int cg = c0p / T::kG;
-    const uint4* rec = src + ((size_t)nb * nvox_per_patch + sp) * cg;
+    // group g of the voxel: half (g & 1) of its record in chunk plane g >> 1
+    const uint4* rec = src + ((size_t)nb * (cg / 2) * nvox_per_patch + sp) * 2;
     float acc[OC];
 #pragma unroll
     for (int o = 0; o < OC; ++o) acc[o] = bias[o];
     for (int g = 0; g < cg; ++g) {
         float f[T::kG];
-        T::unpack(rec[g], f);
+        T::unpack(rec[(size_t)(g >> 1) * nvox_per_patch * 2 + (g & 1)], f);
 #pragma unroll
         for (int o = 0; o < OC; ++o)
 #pragma unroll
@@ -441,10 +452,11 @@ int launch_convt2(int dtype, const void* src, const void* weights, const float* 
 int launch_maxpool2(int dtype, const void* src, void* dst, int n, int d, int h, int w,
                     int c, hipStream_t stream) {
     EXA_CHECK_ARG(d % 2 == 0 && h % 2 == 0 && w % 2 == 0, "maxpool: odd size %dx%dx%d", d, h, w);
-    const int cg = c * dtype_size(dtype) / 16;
+    constexpr int cg = 2;                              // 16-byte groups of a 32-byte record
+    const int nv = n * (c * dtype_size(dtype) / 32);   // chunk planes = independent volumes
     const int row = (w / 2) * cg;
-    EXA_CHECK_ARG((long long)n * (d / 2) <= 65535 && h / 2 <= 65535, "maxpool: grid too large");
-    dim3 grid((row + 63) / 64, h / 2, n * (d / 2));
+    EXA_CHECK_ARG((long long)nv * (d / 2) <= 65535 && h / 2 <= 65535, "maxpool: grid too large");
+    dim3 grid((row + 63) / 64, h / 2, nv * (d / 2));
     DISPATCH_T(dtype, (maxpool2_kernel<T><<<grid, 64, 0, stream>>>(
                           static_cast<const uint4*>(src), static_cast<uint4*>(dst), d, h, w, cg)));
     EXA_CHECK_HIP(hipGetLastError());
@@ -453,10 +465,11 @@ int launch_maxpool2(int dtype, const void* src, void* dst, int n, int d, int h, 
 
 int launch_upsample2(int dtype, const void* src, void* dst, int n, int d, int h, int w,
                      int c, hipStream_t stream) {
-    const int cg = c * dtype_size(dtype) / 16;
+    constexpr int cg = 2;                              // 16-byte groups of a 32-byte record
+    const int nv = n * (c * dtype_size(dtype) / 32);   // chunk planes = independent volumes
     const int row = (w * 2) * cg;
-    EXA_CHECK_ARG((long long)n * d * 2 <= 65535 && h * 2 <= 65535, "upsample: grid too large");
-    dim3 grid((row + 127) / 128, h * 2, n * d * 2);
+    EXA_CHECK_ARG((long long)nv * d * 2 <= 65535 && h * 2 <= 65535, "upsample: grid too large");
+    dim3 grid((row + 127) / 128, h * 2, nv * d * 2);
     DISPATCH_T(dtype, (upsample2_kernel<T><<<grid, 128, 0, stream>>>(
                           static_cast<const uint4*>(src), static_cast<uint4*>(dst), d, h, w, cg)));
     EXA_CHECK_HIP(hipGetLastError());

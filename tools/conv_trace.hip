@@ -4,7 +4,7 @@
 // life goes (prologue latency, MFMA loop, barriers, epilogue).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DEXASPIM_TRACE tools/conv_trace.hip \
 //         aind_exaspim_neuron_segmentation_amd/csrc/plan.cpp -x hip -o tools/conv_trace
-//   tools/conv_trace <ca> <cb> <cout> <edge> <batch> <out.bin>
+//   tools/conv_trace <ca> <cb> <cout> <edge> <batch> <out.bin> [kernel variant]
 #include "../aind_exaspim_neuron_segmentation_amd/csrc/conv3d.hip"
 
 #include <cstdlib>
@@ -21,6 +21,7 @@
 
 int main(int argc, char** argv) {
     if (argc < 7) return 2;
+    if (argc > 7) exaspim::g_variant = atoi(argv[7]);
     const int ca = atoi(argv[1]), cb = atoi(argv[2]), cout = atoi(argv[3]);
     const int edge = atoi(argv[4]), n = atoi(argv[5]);
     const size_t vox = (size_t)n * edge * edge * edge;
@@ -45,7 +46,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&bias, cout * 4));
     CK(hipMemset(bias, 0, cout * 4));
     CK(hipMalloc(&dst, vox * cout * 2));
-    const size_t nwg = (size_t)n * ((edge + 5) / 6) * (edge / 8) * (edge / 16);
+    const size_t nwg = (size_t)n * ((edge + 5) / 6) * (edge / 8) * (edge / 16);   // tiles
     unsigned long long* trace;
     const size_t tbytes = nwg * 4 * 16 * 8;
     CK(hipMalloc(&trace, tbytes));
@@ -54,6 +55,27 @@ int main(int argc, char** argv) {
     exaspim::ConvArgs a{};
     a.src_a = a_dev; a.src_b = b_dev; a.ca = ca; a.cb = cb; a.weights = w_dev; a.bias = bias;
     a.dst = dst; a.cout = cout; a.n = n; a.d = a.h = a.w = edge; a.slope = 0.01f;
+    if (exaspim::g_variant != 0) {   // the variant must reproduce the library kernel bit for bit
+        const int v = exaspim::g_variant;
+        void* ref;
+        CK(hipMalloc(&ref, vox * cout * 2));
+        exaspim::g_variant = 0;
+        a.dst = ref;
+        if (exaspim::launch_conv3x3x3(EXASPIM_DT_BF16, a, 0)) return 1;
+        exaspim::g_variant = v;
+        a.dst = dst;
+        CK(hipMemset(dst, 0xff, vox * cout * 2));
+        if (exaspim::launch_conv3x3x3(EXASPIM_DT_BF16, a, 0)) return 1;
+        CK(hipDeviceSynchronize());
+        std::vector<uint16_t> h0(vox * cout), h1(vox * cout);
+        CK(hipMemcpy(h0.data(), ref, vox * cout * 2, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(h1.data(), dst, vox * cout * 2, hipMemcpyDeviceToHost));
+        size_t bad = 0;
+        for (size_t i = 0; i < h0.size(); ++i) bad += h0[i] != h1[i];
+        printf("variant %d vs library kernel: %zu of %zu values differ\n", v, bad, h0.size());
+        CK(hipFree(ref));
+        if (bad) return 3;
+    }
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int it = 0; it < 4; ++it) {   // warm-up, untraced
@@ -61,13 +83,14 @@ int main(int argc, char** argv) {
     }
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
-    for (int it = 0; it < 10; ++it) exaspim::launch_conv3x3x3(EXASPIM_DT_BF16, a, 0);
+    const int reps = getenv("CONV_TRACE_REPEAT") ? atoi(getenv("CONV_TRACE_REPEAT")) : 10;
+    for (int it = 0; it < reps; ++it) exaspim::launch_conv3x3x3(EXASPIM_DT_BF16, a, 0);
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     float ms = 0;
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double flop = 2.0 * 27 * cin * cout * (double)vox;
-    printf("untraced: %.3f ms per launch, %.1f TFLOP/s\n", ms / 10, flop / (ms / 10 * 1e-3) * 1e-12);
+    printf("untraced: %.3f ms per launch, %.1f TFLOP/s\n", ms / reps, flop / (ms / reps * 1e-3) * 1e-12);
     a.trace = trace;
     CK(hipEventRecord(e0, 0));
     exaspim::launch_conv3x3x3(EXASPIM_DT_BF16, a, 0);
