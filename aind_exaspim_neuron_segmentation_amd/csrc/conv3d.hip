@@ -363,6 +363,9 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
     constexpr int HXP = HX;                // row stride (slots)
     constexpr int PLANE = HY * HXP;        // slots per halo plane
     constexpr int HVP = HZ * PLANE;        // slots per channel group
+    // stride between the two channel-group planes: an odd multiple of 128 bytes, so the
+    // lane pair that stages one voxel (group 0, group 1) writes different LDS banks
+    constexpr int GS = HVP + (24 - HVP % 16) % 16;
     constexpr int NWAVES = TY * TX / 32;
     constexpr int NTHREADS = NWAVES * 64;
     constexpr int NPAIR = 2 * HY * HX;     // (column, group) pairs of the halo block
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
     constexpr int EPI_UNITS = NWAVES * 32 * RECP / 16;
     constexpr int WUNITS = 27 * 64;        // the chunk's weight fragments in LDS
     constexpr int WITEMS = (WUNITS + NTHREADS - 1) / NTHREADS;
-    constexpr int XUNITS = 2 * HVP > EPI_UNITS ? 2 * HVP : EPI_UNITS;
+    constexpr int XUNITS = 2 * GS > EPI_UNITS ? 2 * GS : EPI_UNITS;
     constexpr int LDS_UNITS = XUNITS + WUNITS;
     constexpr int NS = 9 * HZ;             // steps per chunk
     constexpr int R = D + 1;               // operand ring
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
     };
 
     const int pos = wave * 32 + r;  // this lane's position inside the plane
-    const int col = (pos / TX) * HXP + (pos % TX) + half * HVP;
+    const int col = (pos / TX) * HXP + (pos % TX) + half * GS;
 
     // ---- staging map ----------------------------------------------------------
     // primary: thread t < NPAIR moves pair t = (column t / 2, group t & 1), all HZ
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
     const size_t patch_vox = (size_t)a.d * plane_vox;
     const bool p_ok = tid < NPAIR;
     const int p_hy = (tid >> 1) / HX, p_hx = (tid >> 1) % HX, p_kg = tid & 1;
-    const int p_slot = p_kg * HVP + p_hy * HXP + p_hx;
+    const int p_slot = p_kg * GS + p_hy * HXP + p_hx;
     unsigned p_voff;      // byte offset inside a z-plane of a chunk plane (or out of range)
     unsigned s_voff[SEC > 0 ? SEC : 1];
     int s_slot[SEC > 0 ? SEC : 1];
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
         const int q = tid + k * NTHREADS;
         const int pr = NTHREADS + q % REM, hz = q / REM;
         const int c = pr >> 1, kg = pr & 1;
-        s_slot[k] = q < REM * HZ ? kg * HVP + hz * PLANE + (c / HX) * HXP + c % HX : -1;
+        s_slot[k] = q < REM * HZ ? kg * GS + hz * PLANE + (c / HX) * HXP + c % HX : -1;
     }
     auto set_offsets = [&](const Tile& t) {
         {
@@ -470,6 +473,12 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
     // the slice's folded bias, kept in LDS: every tile's accumulators start from it
     __shared__ __attribute__((aligned(16))) float bias_s[32];
     if (tid < 32) bias_s[tid] = a.bias[ntile0 * 32 + tid];
+    // the fused head's weights and bias live there too (read back once per tile)
+    __shared__ __attribute__((aligned(16))) float head_s[HEAD > 0 ? HEAD * 32 + 4 : 4];
+    if (HEAD > 0) {
+        if (tid < HEAD * 32) head_s[tid] = a.head_w[tid];
+        if (tid < HEAD) head_s[HEAD * 32 + tid] = a.head_b[tid];
+    }
 
     const int nchunks = (a.ca + a.cb) / KC;
     uint4 stg[NITEMS + WITEMS];  // halo pieces, then weight fragments
@@ -618,38 +627,41 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
             // ---- fused head: OutConv 1x1x1 (+ sigmoid) on the accumulators -----------
             // lane (voxel r, half h) holds channels 8q + 4h + j of its voxel: a 16-term
             // partial dot product per output, completed by the other half-wave.
-            float hw[HEAD > 0 ? HEAD : 1][16];
+            // Channel quads outermost, so only 4 weights per output are live at a time
+            // (the next tile's staged pieces occupy most of the register file here).
+            float part[TZ][HEAD > 0 ? HEAD : 1];
+#pragma unroll
+            for (int z = 0; z < TZ; ++z)
+#pragma unroll
+                for (int o = 0; o < HEAD; ++o) part[z][o] = 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+                float4 hw[HEAD > 0 ? HEAD : 1];
 #pragma unroll
-                for (int o = 0; o < HEAD; ++o) {
-                    const float4 t = *reinterpret_cast<const float4*>(a.head_w + o * 32 + 8 * q + 4 * half);
-                    hw[o][4 * q + 0] = t.x; hw[o][4 * q + 1] = t.y;
-                    hw[o][4 * q + 2] = t.z; hw[o][4 * q + 3] = t.w;
+                for (int o = 0; o < HEAD; ++o)
+                    hw[o] = *reinterpret_cast<const float4*>(head_s + o * 32 + 8 * q + 4 * half);
+#pragma unroll
+                for (int z = 0; z < TZ; ++z) {
+                    float v0 = acc[z][4 * q + 0], v1 = acc[z][4 * q + 1];
+                    float v2 = acc[z][4 * q + 2], v3 = acc[z][4 * q + 3];
+                    v0 = fmaxf(v0, v0 * a.slope);
+                    v1 = fmaxf(v1, v1 * a.slope);
+                    v2 = fmaxf(v2, v2 * a.slope);
+                    v3 = fmaxf(v3, v3 * a.slope);
+#pragma unroll
+                    for (int o = 0; o < HEAD; ++o)
+                        part[z][o] = fmaf(v3, hw[o].w, fmaf(v2, hw[o].z, fmaf(v1, hw[o].y, fmaf(v0, hw[o].x, part[z][o]))));
                 }
             }
-            float hb[HEAD > 0 ? HEAD : 1];
-#pragma unroll
-            for (int o = 0; o < HEAD; ++o) hb[o] = a.head_b[o];
             const size_t plane = (size_t)a.h * a.w;
             const int gy = cur.y0 + pos / TX, gx = cur.x0 + pos % TX;
 #pragma unroll
             for (int z = 0; z < TZ; ++z) {
-                float part[HEAD > 0 ? HEAD : 1];
-#pragma unroll
-                for (int o = 0; o < HEAD; ++o) part[o] = 0.f;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    float v = acc[z][k];
-                    v = fmaxf(v, v * a.slope);
-#pragma unroll
-                    for (int o = 0; o < HEAD; ++o) part[o] = fmaf(v, hw[o][k], part[o]);
-                }
                 const int gz = cur.z0 + z;
                 const bool ok = gz < a.d && gy < a.h && gx < a.w;
 #pragma unroll
                 for (int o = 0; o < HEAD; ++o) {
-                    float t = part[o] + __shfl_xor(part[o], 32) + hb[o];
+                    float t = part[z][o] + __shfl_xor(part[z][o], 32) + head_s[HEAD * 32 + o];
                     if (a.head_sigmoid) t = 1.f / (1.f + expf(-t));
                     // outputs are dealt to the two half-waves so both store
                     if (ok && (o & 1) == half)
@@ -748,7 +760,7 @@ static int launch_zpipe(const ConvArgs& a, hipStream_t stream) {
     if (wgs < 8) wgs = 8;
     if (wgs > blocks) wgs = blocks;
 #ifdef EXASPIM_TRACE
-    if (g_variant >= 10) wgs = blocks;
+    if (g_variant >= 10 && g_variant < 20) wgs = blocks;
 #endif
     dim3 grid((unsigned)wgs, slices);
     conv3x3x3_zpipe<Tag, TZ, TY, TX, MINW, D, HEAD><<<grid, TY * TX * 2, 0, stream>>>(a, tz, ty, tx);
@@ -809,6 +821,9 @@ static int launch_typed(const ConvArgs& a, hipStream_t stream) {
     // a 96^3 patch; any other size runs on the closest shape with masking.
     if (a.w >= 16 && a.w % 16 == 0) {
         // 32-cout slices: z-column tiles with the chunk's weights shared through LDS
+#ifdef EXASPIM_TRACE
+        if (g_variant >= 20) return launch_zpipe_d<Tag, 6>(a, stream);
+#endif
         if (a.cout % 64 != 0) {
             // 6-plane tiles when the depth divides (96, 48, 24): more dz reuse per LDS read
             if (a.d % 6 == 0) return launch_zpipe_d<Tag, 6>(a, stream);

@@ -288,19 +288,20 @@ __global__ __launch_bounds__(256) void convt2_kernel(const uint4* __restrict__ s
 }
 
 // ---- max-pool 2x2x2 ----------------------------------------------------------
-// Grid: x = 16-byte pieces of one output row, y = output row, z = patch * depth.
-// All per-thread index arithmetic is 32-bit; the row/plane split is scalar.
+// Grid: x = (volume, output plane), y = blocks of 16-byte pieces of that plane, so
+// small pyramid levels still fill their blocks. Index arithmetic is 32-bit; the
+// volume/plane split is scalar.
 template <typename T>
-__global__ __launch_bounds__(64) void maxpool2_kernel(const uint4* __restrict__ src,
-                                                      uint4* __restrict__ dst, int d, int h,
-                                                      int w, int cg) {
-    // d,h,w: input size; cg: 16-byte groups per voxel
+__global__ __launch_bounds__(256) void maxpool2_kernel(const uint4* __restrict__ src,
+                                                       uint4* __restrict__ dst, int d, int h,
+                                                       int w, int cg) {
+    // d,h,w: input size; cg: 16-byte groups per voxel record
     const int od = d / 2, oh = h / 2, ow = w / 2;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // piece inside the output row
-    if (i >= ow * cg) return;
-    const int x = i / cg, g = i - x * cg;
-    const int y = blockIdx.y;
-    const int nb = blockIdx.z / od, z = blockIdx.z - nb * od;
+    const int i = blockIdx.y * blockDim.x + threadIdx.x;  // piece inside the output plane
+    if (i >= oh * ow * cg) return;
+    const int y = i / (ow * cg), ix = i - y * (ow * cg);
+    const int x = ix / cg, g = ix - x * cg;
+    const int nb = blockIdx.x / od, z = blockIdx.x - nb * od;
     float m[T::kG];
 #pragma unroll
     for (int j = 0; j < T::kG; ++j) m[j] = -INFINITY;
@@ -332,17 +333,17 @@ __device__ __forceinline__ void lerp_coord(int o, int in, int out, int& i0, int&
     l1 = fminf(fmaxf(s - (float)i0, 0.f), 1.f);
 }
 
-// Same grid shape as the pool: the z and y interpolation coordinates are scalar.
+// Same grid shape as the pool: the z interpolation coordinate is scalar.
 template <typename T>
-__global__ __launch_bounds__(128) void upsample2_kernel(const uint4* __restrict__ src,
+__global__ __launch_bounds__(256) void upsample2_kernel(const uint4* __restrict__ src,
                                                         uint4* __restrict__ dst, int d, int h,
                                                         int w, int cg) {
     const int od = d * 2, oh = h * 2, ow = w * 2;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ow * cg) return;
-    const int x = i / cg, g = i - x * cg;
-    const int y = blockIdx.y;
-    const int nb = blockIdx.z / od, z = blockIdx.z - nb * od;
+    const int i = blockIdx.y * blockDim.x + threadIdx.x;  // piece inside the output plane
+    if (i >= oh * ow * cg) return;
+    const int y = i / (ow * cg), ix = i - y * (ow * cg);
+    const int x = ix / cg, g = ix - x * cg;
+    const int nb = blockIdx.x / od, z = blockIdx.x - nb * od;
     int z0, z1, y0, y1, x0, x1;
     float lz, ly, lx;
     lerp_coord(z, d, od, z0, z1, lz);
@@ -454,10 +455,11 @@ int launch_maxpool2(int dtype, const void* src, void* dst, int n, int d, int h, 
     EXA_CHECK_ARG(d % 2 == 0 && h % 2 == 0 && w % 2 == 0, "maxpool: odd size %dx%dx%d", d, h, w);
     constexpr int cg = 2;                              // 16-byte groups of a 32-byte record
     const int nv = n * (c * dtype_size(dtype) / 32);   // chunk planes = independent volumes
-    const int row = (w / 2) * cg;
-    EXA_CHECK_ARG((long long)nv * (d / 2) <= 65535 && h / 2 <= 65535, "maxpool: grid too large");
-    dim3 grid((row + 63) / 64, h / 2, nv * (d / 2));
-    DISPATCH_T(dtype, (maxpool2_kernel<T><<<grid, 64, 0, stream>>>(
+    const long long plane = (long long)(h / 2) * (w / 2) * cg;
+    EXA_CHECK_ARG((long long)nv * (d / 2) <= 0x7fffffffLL && (plane + 255) / 256 <= 65535,
+                  "maxpool: grid too large");
+    dim3 grid(nv * (d / 2), (unsigned)((plane + 255) / 256));
+    DISPATCH_T(dtype, (maxpool2_kernel<T><<<grid, 256, 0, stream>>>(
                           static_cast<const uint4*>(src), static_cast<uint4*>(dst), d, h, w, cg)));
     EXA_CHECK_HIP(hipGetLastError());
     return EXASPIM_OK;
@@ -467,10 +469,11 @@ int launch_upsample2(int dtype, const void* src, void* dst, int n, int d, int h,
                      int c, hipStream_t stream) {
     constexpr int cg = 2;                              // 16-byte groups of a 32-byte record
     const int nv = n * (c * dtype_size(dtype) / 32);   // chunk planes = independent volumes
-    const int row = (w * 2) * cg;
-    EXA_CHECK_ARG((long long)nv * d * 2 <= 65535 && h * 2 <= 65535, "upsample: grid too large");
-    dim3 grid((row + 127) / 128, h * 2, nv * d * 2);
-    DISPATCH_T(dtype, (upsample2_kernel<T><<<grid, 128, 0, stream>>>(
+    const long long plane = (long long)(h * 2) * (w * 2) * cg;
+    EXA_CHECK_ARG((long long)nv * d * 2 <= 0x7fffffffLL && (plane + 255) / 256 <= 65535,
+                  "upsample: grid too large");
+    dim3 grid(nv * d * 2, (unsigned)((plane + 255) / 256));
+    DISPATCH_T(dtype, (upsample2_kernel<T><<<grid, 256, 0, stream>>>(
                           static_cast<const uint4*>(src), static_cast<uint4*>(dst), d, h, w, cg)));
     EXA_CHECK_HIP(hipGetLastError());
     return EXASPIM_OK;
