@@ -324,34 +324,40 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const uint4* __restrict__
 // ---- trilinear x2, align_corners=True ---------------------------------------
 // torch (ATen UpSample.h): scale = (in - 1) / (out - 1) in float; src = scale *
 // dst_index; i0 = floor(src) clamped; lambda = src - i0 clamped to [0, 1];
-// i1 = min(i0 + 1, in - 1).
-__device__ __forceinline__ void lerp_coord(int o, int in, int out, int& i0, int& i1, float& l1) {
-    const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+// i1 = min(i0 + 1, in - 1). The three scales are computed on the host with the
+// same float division.
+__device__ __forceinline__ void lerp_coord(int o, int in, float scale, int& i0, int& i1, float& l1) {
     const float s = scale * (float)o;
     i0 = min((int)floorf(s), in - 1);
     i1 = min(i0 + 1, in - 1);
     l1 = fminf(fmaxf(s - (float)i0, 0.f), 1.f);
 }
 
-// Same grid shape as the pool: the z interpolation coordinate is scalar.
+// Same grid shape as the pool: the z interpolation coordinate is scalar. "row_magic"
+// = floor(2^32 / (ow * cg)) + 1 turns the row split into a multiply-high (exact for the
+// plane sizes the launcher admits).
 template <typename T>
 __global__ __launch_bounds__(256) void upsample2_kernel(const uint4* __restrict__ src,
                                                         uint4* __restrict__ dst, int d, int h,
-                                                        int w, int cg) {
+                                                        int w, unsigned row_magic, float sz,
+                                                        float sy, float sx) {
+    constexpr int cg = 2;  // 16-byte groups of a 32-byte record
     const int od = d * 2, oh = h * 2, ow = w * 2;
-    const int i = blockIdx.y * blockDim.x + threadIdx.x;  // piece inside the output plane
-    if (i >= oh * ow * cg) return;
-    const int y = i / (ow * cg), ix = i - y * (ow * cg);
-    const int x = ix / cg, g = ix - x * cg;
+    const unsigned i = blockIdx.y * blockDim.x + threadIdx.x;  // piece inside the output plane
+    if (i >= (unsigned)(oh * ow * cg)) return;
+    const int y = (int)__umulhi(i, row_magic), ix = (int)i - y * (ow * cg);
+    const int x = ix >> 1, g = ix & 1;
     const int nb = blockIdx.x / od, z = blockIdx.x - nb * od;
     int z0, z1, y0, y1, x0, x1;
     float lz, ly, lx;
-    lerp_coord(z, d, od, z0, z1, lz);
-    lerp_coord(y, h, oh, y0, y1, ly);
-    lerp_coord(x, w, ow, x0, x1, lx);
-    float acc[T::kG];
+    lerp_coord(z, d, sz, z0, z1, lz);
+    lerp_coord(y, h, sy, y0, y1, ly);
+    lerp_coord(x, w, sx, x0, x1, lx);
+    // the eight corner weights, then a packed (2 x fp32 per instruction) weighted sum
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 acc[T::kG / 2];
 #pragma unroll
-    for (int j = 0; j < T::kG; ++j) acc[j] = 0.f;
+    for (int j = 0; j < T::kG / 2; ++j) acc[j] = (f2){0.f, 0.f};
     const int zs[2] = {z0, z1}, ys[2] = {y0, y1}, xs[2] = {x0, x1};
     const float wz[2] = {1.f - lz, lz}, wy[2] = {1.f - ly, ly}, wx[2] = {1.f - lx, lx};
     const uint4* base = src + (size_t)nb * d * h * w * cg + g;
@@ -366,11 +372,16 @@ __global__ __launch_bounds__(256) void upsample2_kernel(const uint4* __restrict_
                 float f[T::kG];
                 T::unpack(row[xs[c] * cg], f);
                 const float wgt = wzy * wx[c];
+                const f2 w2 = {wgt, wgt};
 #pragma unroll
-                for (int j = 0; j < T::kG; ++j) acc[j] = fmaf(wgt, f[j], acc[j]);
+                for (int j = 0; j < T::kG / 2; ++j)
+                    acc[j] = __builtin_elementwise_fma(w2, (f2){f[2 * j], f[2 * j + 1]}, acc[j]);
             }
         }
-    dst[((((size_t)nb * od + z) * oh + y) * ow + x) * cg + g] = T::pack(acc);
+    float out[T::kG];
+#pragma unroll
+    for (int j = 0; j < T::kG / 2; ++j) { out[2 * j] = acc[j].x; out[2 * j + 1] = acc[j].y; }
+    dst[((((size_t)nb * od + z) * oh + y) * ow + x) * cg + g] = T::pack(out);
 }
 
 // ---- head: 1x1x1 conv (+ sigmoid), channels-last -> NCDHW float32 -----------
@@ -470,11 +481,16 @@ int launch_upsample2(int dtype, const void* src, void* dst, int n, int d, int h,
     constexpr int cg = 2;                              // 16-byte groups of a 32-byte record
     const int nv = n * (c * dtype_size(dtype) / 32);   // chunk planes = independent volumes
     const long long plane = (long long)(h * 2) * (w * 2) * cg;
-    EXA_CHECK_ARG((long long)nv * d * 2 <= 0x7fffffffLL && (plane + 255) / 256 <= 65535,
+    const long long rowp = (long long)(w * 2) * cg;
+    EXA_CHECK_ARG((long long)nv * d * 2 <= 0x7fffffffLL && (plane + 255) / 256 <= 65535 &&
+                      plane * rowp < 0xffffffffLL,
                   "upsample: grid too large");
+    const unsigned row_magic = (unsigned)(0x100000000ULL / (unsigned long long)rowp) + 1u;
+    auto scale = [](int in) { return in > 1 ? (float)(in - 1) / (float)(2 * in - 1) : 0.f; };
     dim3 grid(nv * d * 2, (unsigned)((plane + 255) / 256));
     DISPATCH_T(dtype, (upsample2_kernel<T><<<grid, 256, 0, stream>>>(
-                          static_cast<const uint4*>(src), static_cast<uint4*>(dst), d, h, w, cg)));
+                          static_cast<const uint4*>(src), static_cast<uint4*>(dst), d, h, w,
+                          row_magic, scale(d), scale(h), scale(w))));
     EXA_CHECK_HIP(hipGetLastError());
     return EXASPIM_OK;
 }

@@ -42,7 +42,7 @@ from aind_exaspim_neuron_segmentation_amd.utils import synthetic  # noqa: E402
 
 FLOP_PER_PATCH_96 = 370_145_230_848  # 2 x MAC over the 19 convs
 PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense MFMA, MI355X_MICROARCH.md
-# Launches of the dominant kernel symbol, conv3x3x3_zcol<.., 6, 8, 16, .., HEAD = 0>
+# Launches of the dominant kernel symbol, conv3x3x3_zpipe<.., 6, 8, 16, 2, 4, HEAD = 0>
 # (32-cout layers without the fused head): (bit in the timing mask, Cin, Cout, edge)
 DOMINANT_CONVS = [(0, 32, 32, 96), (14, 64, 32, 48), (15, 64, 32, 96)]  # inc.3, up3.3, up4.0
 
@@ -200,7 +200,7 @@ def main():
             with open(tpath) as f:
                 kernels = json.load(f).get("kernels", {})
             tag = {"bf16": "BF16Tag", "fp16": "F16Tag", "fp32": "F32Tag"}[args.dtype]
-            entry = kernels.get(f"conv3x3x3_zcol<{tag}, 6, 8, 16, 4, 1, 1, 1, 2, 1, true, false, 0>")
+            entry = kernels.get(f"conv3x3x3_zpipe<{tag}, 6, 8, 16, 2, 4, 0>")
             if entry:
                 traffic = entry["hbm_bytes_per_launch"]
         result = {
@@ -229,7 +229,7 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "conv3x3x3_zcol<tile 6x8x16, 32 couts, no head> (launches: inc.3, up3.3, up4.0)",
+                "kernel": "conv3x3x3_zpipe<tile 6x8x16, 32 couts, no head> (launches: inc.3, up3.3, up4.0)",
                 "algorithmic_flop_per_launch": flops / launches if launches else None,
                 "achieved": achieved,
                 "peak": peak,
