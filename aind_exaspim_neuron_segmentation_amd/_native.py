@@ -79,6 +79,9 @@ SIGNATURES = {
     "exaspim_unet_destroy": (None, [_vp]),
     "exaspim_unet_workspace_bytes": (_sz, [_vp, _i32, _i32, _i32, _i32]),
     "exaspim_unet_forward": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "exaspim_unet_forward_trimmed": (
+        _i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]
+    ),
     "exaspim_unet_timing_begin": (_i32, [_vp, ctypes.c_uint32]),
     "exaspim_unet_timing_read": (_i32, [_vp, ctypes.POINTER(ctypes.c_double * 17),
                                         ctypes.POINTER(ctypes.c_int32 * 17)]),

@@ -107,6 +107,10 @@ struct ConvArgs {
     float* head_out = nullptr;      // float (n, head_oc, d, h, w)
     int head_oc = 0;
     int head_sigmoid = 0;
+    // Output voxels closer than "margin" to a face of the patch are not needed by
+    // the caller (predict() trims them, inference.py:161-162): kernels that can
+    // skip them do (the z-column kernel drops whole tiles), the others ignore it.
+    int margin = 0;
 #ifdef EXASPIM_TRACE
     // tools/conv_trace.hip only: 16 x 64-bit cycle stamps per wave (never in the library build)
     unsigned long long* trace = nullptr;
@@ -125,8 +129,9 @@ int launch_convt2(int dtype, const void* src, const void* weights, const float* 
                   int n, int d, int h, int w, int cin, int cout, hipStream_t stream);
 int launch_maxpool2(int dtype, const void* src, void* dst, int n, int d, int h, int w,
                     int c, hipStream_t stream);  // d,h,w = INPUT size
+// d,h,w = INPUT size; output voxels within "margin" of a face are not computed
 int launch_upsample2(int dtype, const void* src, void* dst, int n, int d, int h, int w,
-                     int c, hipStream_t stream);  // d,h,w = INPUT size
+                     int c, int margin, hipStream_t stream);
 int launch_head(int dtype, const void* src, const float* w, const float* bias,
                 float* out, int n, int d, int h, int wd, int c0p, int out_channels,
                 int apply_sigmoid, hipStream_t stream);

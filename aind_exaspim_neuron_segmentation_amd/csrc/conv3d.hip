@@ -419,9 +419,9 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
     };
     auto tile_at = [&](int id) {
         Tile t;
-        t.x0 = (id % tiles_x) * TX; id /= tiles_x;
-        t.y0 = (id % tiles_y) * TY; id /= tiles_y;
-        t.z0 = (id % tiles_z) * TZ; id /= tiles_z;
+        t.x0 = a.margin + (id % tiles_x) * TX; id /= tiles_x;
+        t.y0 = a.margin + (id % tiles_y) * TY; id /= tiles_y;
+        t.z0 = a.margin + (id % tiles_z) * TZ; id /= tiles_z;
         t.nb = id;
         return t;
     };
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
 #pragma unroll
             for (int z = 0; z < TZ; ++z) {
                 const int gz = cur.z0 + z;
-                const bool ok = gz < a.d && gy < a.h && gx < a.w;
+                const bool ok = gz < a.d - a.margin && gy < a.h - a.margin && gx < a.w - a.margin;
 #pragma unroll
                 for (int o = 0; o < HEAD; ++o) {
                     float t = part[z][o] + __shfl_xor(part[z][o], 32) + head_s[HEAD * 32 + o];
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
 #pragma unroll
                 for (int z = zb; z < zb + TB && z < TZ; ++z) {
                     const int gz = cur.z0 + z;
-                    const bool ok = gz < a.d && ogy < a.h && ogx < a.w;
+                    const bool ok = gz < a.d - a.margin && ogy < a.h - a.margin && ogx < a.w - a.margin;
                     const size_t vox = ((size_t)gz * a.h + ogy) * a.w + ogx;
 #pragma unroll
                     for (int ck = 0; ck < CPT; ++ck) {
@@ -747,7 +747,9 @@ static int resident_workgroups(int per_cu) {
 
 template <typename Tag, int TZ, int TY, int TX, int MINW, int D, int HEAD = 0>
 static int launch_zpipe(const ConvArgs& a, hipStream_t stream) {
-    const int tz = (a.d + TZ - 1) / TZ, ty = (a.h + TY - 1) / TY, tx = (a.w + TX - 1) / TX;
+    // tiles cover the voxels the caller needs, [margin, size - margin) on every axis
+    const int m2 = 2 * a.margin;
+    const int tz = (a.d - m2 + TZ - 1) / TZ, ty = (a.h - m2 + TY - 1) / TY, tx = (a.w - m2 + TX - 1) / TX;
     const long long blocks = (long long)tz * ty * tx * a.n;
     if (blocks <= 0 || blocks > 0x7fffffffLL) {
         set_error("conv: grid of %lld blocks out of range", blocks);
@@ -854,6 +856,8 @@ int launch_conv3x3x3(int dtype, const ConvArgs& a, hipStream_t stream) {
                   "conv: channels (%d,%d)->%d not padded", a.ca, a.cb, a.cout);
     EXA_CHECK_ARG(a.n > 0 && a.d > 0 && a.h > 0 && a.w > 0, "conv: empty input");
     EXA_CHECK_ARG(a.slope >= 0.f && a.slope <= 1.f, "conv: LeakyReLU slope %g outside [0, 1]", a.slope);
+    EXA_CHECK_ARG(a.margin >= 0 && 2 * a.margin < a.d && 2 * a.margin < a.h && 2 * a.margin < a.w,
+                  "conv: margin %d leaves nothing of a %dx%dx%d patch", a.margin, a.d, a.h, a.w);
     EXA_CHECK_ARG(!a.head_out || conv_can_fuse_head(a.cout, a.w, a.head_oc),
                   "conv: fused head needs cout 32, w %% 16 == 0, 1..4 outputs");
     {   // the LDS-DMA staging addresses one patch of one source with 32-bit offsets

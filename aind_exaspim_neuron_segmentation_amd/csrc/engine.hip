@@ -81,7 +81,7 @@ static Workspace make_workspace(const UNetPlan& p, int n, int d, int h, int w) {
 }
 
 static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, int h, int w,
-                   int apply_sigmoid, void* workspace, size_t workspace_bytes,
+                   int apply_sigmoid, int trim, void* workspace, size_t workspace_bytes,
                    hipStream_t stream) {
     const UNetPlan& p = e->plan;
     const Workspace ws = make_workspace(p, n, d, h, w);
@@ -98,9 +98,14 @@ static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, in
 
     // the last conv (up4.3) can run the 1x1x1 head on its accumulators
     const bool fuse_head = conv_can_fuse_head(p.conv[kNumMfmaConvs - 1].cout, w, p.out_channels);
+    // With the head fused, voxels within "trim" of a patch face are never read again:
+    // up4.3 skips them, and up4.0 everything its 3x3x3 consumer does not reach.
+    const bool trimmed = fuse_head && trim > 0 && 2 * trim < d && 2 * trim < h && 2 * trim < w;
     auto conv = [&](int idx, const void* sa, const void* sb, void* dst, int l) -> int {
         const ConvLayer& L = p.conv[idx];
         ConvArgs a;
+        if (trimmed && idx == kNumMfmaConvs - 1) a.margin = trim;
+        if (trimmed && idx == kNumMfmaConvs - 2) a.margin = trim - 1;
         if (idx == kNumMfmaConvs - 1 && fuse_head) {
             a.head_w = reinterpret_cast<const float*>(e->packed + p.head_w_off);
             a.head_b = reinterpret_cast<const float*>(e->packed + p.head_b_off);
@@ -157,8 +162,9 @@ static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, in
                               reinterpret_cast<const float*>(e->packed + U.b_off), A(l), n,
                               d >> (l + 1), h >> (l + 1), w >> (l + 1), U.cin, U.cout, stream));
         } else {
+            // up4.0 reads the upsampled tensor one voxel beyond its own trimmed output
             RUN(launch_upsample2(dt, prev, A(l), n, d >> (l + 1), h >> (l + 1), w >> (l + 1), L0.cb,
-                                 stream));
+                                 trimmed && l == 0 && trim > 2 ? trim - 2 : 0, stream));
         }
         RUN(conv(i0, skip(l), A(l), B(l), l));
         RUN(conv(i0 + 1, B(l), nullptr, A(l), l));
@@ -305,6 +311,21 @@ extern "C" int exaspim_unet_forward(exaspim_unet* h, const float* x_dev, float* 
     EXA_CHECK_ARG(level_dims_ok(d, hgt, w),
                   "forward: patch %dx%dx%d: every dimension must be a positive multiple of 16",
                   d, hgt, w);
-    return forward(h, x_dev, out_dev, n, d, hgt, w, apply_sigmoid, workspace_dev, workspace_bytes,
+    return forward(h, x_dev, out_dev, n, d, hgt, w, apply_sigmoid, 0, workspace_dev, workspace_bytes,
                    (hipStream_t)stream);
+}
+
+extern "C" int exaspim_unet_forward_trimmed(exaspim_unet* h, const float* x_dev, float* out_dev,
+                                            int32_t n, int32_t d, int32_t hgt, int32_t w,
+                                            int32_t apply_sigmoid, int32_t trim,
+                                            void* workspace_dev, size_t workspace_bytes,
+                                            void* stream) {
+    EXA_CHECK_ARG(h && x_dev && out_dev && workspace_dev, "forward: NULL pointer");
+    EXA_CHECK_ARG(n > 0, "forward: empty batch");
+    EXA_CHECK_ARG(trim >= 0, "forward: negative trim %d", trim);
+    EXA_CHECK_ARG(level_dims_ok(d, hgt, w),
+                  "forward: patch %dx%dx%d: every dimension must be a positive multiple of 16",
+                  d, hgt, w);
+    return forward(h, x_dev, out_dev, n, d, hgt, w, apply_sigmoid, trim, workspace_dev,
+                   workspace_bytes, (hipStream_t)stream);
 }

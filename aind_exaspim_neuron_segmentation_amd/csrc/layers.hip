@@ -340,14 +340,16 @@ template <typename T>
 __global__ __launch_bounds__(256) void upsample2_kernel(const uint4* __restrict__ src,
                                                         uint4* __restrict__ dst, int d, int h,
                                                         int w, unsigned row_magic, float sz,
-                                                        float sy, float sx) {
+                                                        float sy, float sx, int margin) {
+    // output voxels closer than "margin" to a face are not needed by the caller
     constexpr int cg = 2;  // 16-byte groups of a 32-byte record
     const int od = d * 2, oh = h * 2, ow = w * 2;
-    const unsigned i = blockIdx.y * blockDim.x + threadIdx.x;  // piece inside the output plane
-    if (i >= (unsigned)(oh * ow * cg)) return;
-    const int y = (int)__umulhi(i, row_magic), ix = (int)i - y * (ow * cg);
-    const int x = ix >> 1, g = ix & 1;
-    const int nb = blockIdx.x / od, z = blockIdx.x - nb * od;
+    const int nz = od - 2 * margin, ny = oh - 2 * margin, rowp = (ow - 2 * margin) * cg;
+    const unsigned i = blockIdx.y * blockDim.x + threadIdx.x;  // piece inside the needed plane
+    if (i >= (unsigned)(ny * rowp)) return;
+    const int yy = (int)__umulhi(i, row_magic), ix = (int)i - yy * rowp;
+    const int y = margin + yy, x = margin + (ix >> 1), g = ix & 1;
+    const int nb = blockIdx.x / nz, z = margin + blockIdx.x - nb * nz;
     int z0, z1, y0, y1, x0, x1;
     float lz, ly, lx;
     lerp_coord(z, d, sz, z0, z1, lz);
@@ -477,20 +479,21 @@ int launch_maxpool2(int dtype, const void* src, void* dst, int n, int d, int h, 
 }
 
 int launch_upsample2(int dtype, const void* src, void* dst, int n, int d, int h, int w,
-                     int c, hipStream_t stream) {
+                     int c, int margin, hipStream_t stream) {
+    if (margin < 0 || margin >= d || margin >= h || margin >= w) margin = 0;
     constexpr int cg = 2;                              // 16-byte groups of a 32-byte record
     const int nv = n * (c * dtype_size(dtype) / 32);   // chunk planes = independent volumes
-    const long long plane = (long long)(h * 2) * (w * 2) * cg;
-    const long long rowp = (long long)(w * 2) * cg;
-    EXA_CHECK_ARG((long long)nv * d * 2 <= 0x7fffffffLL && (plane + 255) / 256 <= 65535 &&
-                      plane * rowp < 0xffffffffLL,
+    const long long plane = (long long)(h * 2 - 2 * margin) * (w * 2 - 2 * margin) * cg;
+    const long long rowp = (long long)(w * 2 - 2 * margin) * cg;
+    const long long planes = (long long)nv * (d * 2 - 2 * margin);
+    EXA_CHECK_ARG(planes <= 0x7fffffffLL && (plane + 255) / 256 <= 65535 && plane * rowp < 0xffffffffLL,
                   "upsample: grid too large");
     const unsigned row_magic = (unsigned)(0x100000000ULL / (unsigned long long)rowp) + 1u;
     auto scale = [](int in) { return in > 1 ? (float)(in - 1) / (float)(2 * in - 1) : 0.f; };
-    dim3 grid(nv * d * 2, (unsigned)((plane + 255) / 256));
+    dim3 grid((unsigned)planes, (unsigned)((plane + 255) / 256));
     DISPATCH_T(dtype, (upsample2_kernel<T><<<grid, 256, 0, stream>>>(
                           static_cast<const uint4*>(src), static_cast<uint4*>(dst), d, h, w,
-                          row_magic, scale(d), scale(h), scale(w))));
+                          row_magic, scale(d), scale(h), scale(w), margin)));
     EXA_CHECK_HIP(hipGetLastError());
     return EXASPIM_OK;
 }

@@ -214,7 +214,7 @@ class UNet3D(nn.Module):
         return ws
 
     # ---- forward -----------------------------------------------------------
-    def run(self, x, apply_sigmoid=False, out=None):
+    def run(self, x, apply_sigmoid=False, out=None, trim=0):
         """
         Runs the network on a float32 device tensor of shape (B, 1, D, H, W).
 
@@ -226,6 +226,10 @@ class UNet3D(nn.Module):
             Fuse the sigmoid of inference.py:158 into the head. Default False.
         out : torch.Tensor, optional
             Preallocated (B, C, D, H, W) float32 output.
+        trim : int, optional
+            The caller discards the outputs within "trim" voxels of every patch
+            face (inference.py:161-162), so they are not computed and those
+            voxels of the result are undefined. Default is 0 (everything).
 
         Returns
         -------
@@ -259,11 +263,11 @@ class UNet3D(nn.Module):
                     (n, self.output_channels, d, h, w), dtype=torch.float32, device=device
                 )
             _native.check(
-                _native.lib().exaspim_unet_forward(
+                _native.lib().exaspim_unet_forward_trimmed(
                     self._engine, x.data_ptr(), out.data_ptr(), n, d, h, w,
-                    1 if apply_sigmoid else 0, ws.data_ptr(), ws.numel(), stream,
+                    1 if apply_sigmoid else 0, int(trim), ws.data_ptr(), ws.numel(), stream,
                 ),
-                "exaspim_unet_forward",
+                "exaspim_unet_forward_trimmed",
             )
         return out
 

@@ -45,6 +45,7 @@ PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense MFMA, MI3
 # Launches of the dominant kernel symbol, conv3x3x3_zpipe<.., 6, 8, 16, 2, 4, HEAD = 0>
 # (32-cout layers without the fused head): (bit in the timing mask, Cin, Cout, edge)
 DOMINANT_CONVS = [(0, 32, 32, 96), (14, 64, 32, 48), (15, 64, 32, 96)]  # inc.3, up3.3, up4.0
+TRIM = 8  # predict()'s default (inference.py:38)
 
 
 def parse_args():
@@ -184,7 +185,10 @@ def main():
         k_ms = sum(ms[b] for b, _, _, _ in DOMINANT_CONVS)
         flops = 0.0
         for b, cin, cout, edge in DOMINANT_CONVS:
-            flops += cnt[b] * 2.0 * 27 * cin * cout * args.batch * edge ** 3
+            # up4.0 (bit 15) only computes what up4.3 reads of the voxels predict() keeps:
+            # trim - 1 voxels less on every face (exaspim_unet_forward_trimmed)
+            need = edge - 2 * (TRIM - 1) if b == 15 else edge
+            flops += cnt[b] * 2.0 * 27 * cin * cout * args.batch * need ** 3
         # the last batch of a step may be short; scale by the real patch count
         patches_per_step = len(shard.starts)
         full_batches = -(-patches_per_step // args.batch)

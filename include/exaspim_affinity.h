@@ -130,6 +130,17 @@ int exaspim_unet_forward(exaspim_unet* h, const float* x_dev, float* out_dev,
                          int32_t apply_sigmoid, void* workspace_dev,
                          size_t workspace_bytes, void* stream);
 
+/* The same forward pass for a caller that discards the outputs within "trim"
+ * voxels of every patch face, as _predict_batch does (inference.py:161-162:
+ * outputs[..., trim:-trim, trim:-trim, trim:-trim]). Those voxels of out_dev are
+ * left untouched, and the last two convolutions skip the work that only they
+ * would have needed; every other voxel is bit-identical to exaspim_unet_forward.
+ * trim = 0, or a trim that would leave nothing, is the full forward pass. */
+int exaspim_unet_forward_trimmed(exaspim_unet* h, const float* x_dev, float* out_dev,
+                                 int32_t n, int32_t d, int32_t hgt, int32_t w,
+                                 int32_t apply_sigmoid, int32_t trim, void* workspace_dev,
+                                 size_t workspace_bytes, void* stream);
+
 /* Measurement hooks (bench.py's roofline leg). timing_begin arms HIP-event
  * timing, on the launch stream, of the MFMA convolutions whose bit is set in
  * conv_mask (bit i = i-th 3x3x3 conv after inc.0 in state_dict order: inc.3,

@@ -134,6 +134,23 @@ def test_conv_transpose_half_width(dev, oracle):
     assert np.abs(got - want).max() < 1e-4
 
 
+@pytest.mark.parametrize("cdt", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape,trim", [((96, 96, 96), 8), ((32, 48, 64), 4), ((32, 32, 32), 1),
+                                        ((16, 16, 16), 7)])
+def test_trimmed_forward_is_bit_identical_inside(dev, oracle, cdt, shape, trim):
+    """exaspim_unet_forward_trimmed skips work only the discarded margin needs:
+    every voxel predict() keeps (inference.py:161-162) must not change by a bit."""
+    model, _ = make_model(dev, compute_dtype=cdt)
+    x = normalized_input(oracle, shape, seed=70, n=2).to(dev)
+    full = model.run(x, apply_sigmoid=True)
+    out = torch.full_like(full, -7.0)
+    part = model.run(x, apply_sigmoid=True, out=out, trim=trim)
+    inner = (Ellipsis,) + (slice(trim, -trim),) * 3
+    assert torch.equal(part[inner], full[inner])
+    # the margin is left untouched (predict never reads it)
+    assert bool((part[..., 0, :, :] == -7.0).all()) and bool((part[..., :, :, -1] == -7.0).all())
+
+
 def test_unet_rejects_bad_inputs(dev):
     model, _ = make_model(dev)
     with pytest.raises(RuntimeError, match="Sizes of tensors must match"):
