@@ -71,6 +71,15 @@ __device__ __forceinline__ void mma<F16Tag>(f32x16& acc, const uint4& wf, const 
                                                  __builtin_bit_cast(f16x8, xf), acc, 0, 0, 0);
 }
 
+// LeakyReLU with 0 <= slope <= 1 is max(v, slope * v): one multiply and one bare v_max_f32
+// (fmaxf would put a canonicalising v_max in front of it)
+__device__ __forceinline__ float leaky(float v, float slope) {
+    const float sv = v * slope;
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(sv));
+    return r;
+}
+
 // 16-byte buffer load with hardware range check: an offset at or beyond the
 // descriptor's size returns zeros, which is how the conv's zero padding (and
 // the tail of the staging list) is produced without branches.
@@ -287,10 +296,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
                 // LeakyReLU with 0 <= slope <= 1 is max(v, slope * v)
                 float v0 = acc[mt][nt][4 * q + 0], v1 = acc[mt][nt][4 * q + 1];
                 float v2 = acc[mt][nt][4 * q + 2], v3 = acc[mt][nt][4 * q + 3];
-                v0 = fmaxf(v0, v0 * a.slope);
-                v1 = fmaxf(v1, v1 * a.slope);
-                v2 = fmaxf(v2, v2 * a.slope);
-                v3 = fmaxf(v3, v3 * a.slope);
+                v0 = leaky(v0, a.slope);
+                v1 = leaky(v1, a.slope);
+                v2 = leaky(v2, a.slope);
+                v3 = leaky(v3, a.slope);
                 store4<Tag>(wl, (size_t)(r * RECP) / ES + cl, v0, v1, v2, v3);
             }
         }
@@ -644,10 +653,10 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
                 for (int z = 0; z < TZ; ++z) {
                     float v0 = acc[z][4 * q + 0], v1 = acc[z][4 * q + 1];
                     float v2 = acc[z][4 * q + 2], v3 = acc[z][4 * q + 3];
-                    v0 = fmaxf(v0, v0 * a.slope);
-                    v1 = fmaxf(v1, v1 * a.slope);
-                    v2 = fmaxf(v2, v2 * a.slope);
-                    v3 = fmaxf(v3, v3 * a.slope);
+                    v0 = leaky(v0, a.slope);
+                    v1 = leaky(v1, a.slope);
+                    v2 = leaky(v2, a.slope);
+                    v3 = leaky(v3, a.slope);
 #pragma unroll
                     for (int o = 0; o < HEAD; ++o)
                         part[z][o] = fmaf(v3, hw[o].w, fmaf(v2, hw[o].z, fmaf(v1, hw[o].y, fmaf(v0, hw[o].x, part[z][o]))));
@@ -693,10 +702,10 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
                         // LeakyReLU with 0 <= slope <= 1 is max(v, slope * v)
                         float v0 = acc[z][4 * q + 0], v1 = acc[z][4 * q + 1];
                         float v2 = acc[z][4 * q + 2], v3 = acc[z][4 * q + 3];
-                        v0 = fmaxf(v0, v0 * a.slope);
-                        v1 = fmaxf(v1, v1 * a.slope);
-                        v2 = fmaxf(v2, v2 * a.slope);
-                        v3 = fmaxf(v3, v3 * a.slope);
+                        v0 = leaky(v0, a.slope);
+                        v1 = leaky(v1, a.slope);
+                        v2 = leaky(v2, a.slope);
+                        v3 = leaky(v3, a.slope);
                         store4<Tag>(wl + (z - zb) * (32 * RECP), (size_t)(r * RECP) / ES + cl, v0, v1, v2, v3);
                     }
                 }

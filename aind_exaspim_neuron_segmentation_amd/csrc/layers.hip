@@ -287,6 +287,176 @@ __global__ __launch_bounds__(256) void convt2_kernel(const uint4* __restrict__ s
     }
 }
 
+// ---- inc.0 for the 16-bit modes ------------------------------------------------------
+// The fp32 MFMA above shares the vector ALUs and takes 14 x 16 passes per 32 voxels.
+// With 16-bit storage the layer's result is rounded to 8 or 11 significant bits
+// anyway, so the contraction runs on the 16-bit matrix pipe with split operands:
+// x = x_hi + x_lo and w = w_hi + w_lo (each half a bf16 / f16 number), and
+// x w ~ x_hi w_hi + x_lo w_hi + x_hi w_lo in fp32 accumulation (the dropped terms are
+// below 2^-16 |x w|, still far under the output rounding). K = 27 taps padded to 32 =
+// two MFMA steps; a lane holds taps 8 * (half + 2 * step) .. + 7 of its voxel.
+// LeakyReLU with 0 <= slope <= 1 is max(v, slope * v): a packed multiply and one bare
+// v_max_f32 per value (fmaxf would add a canonicalising v_max in front of each)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t leaky2(f32x2_t v, float slope) {
+    const f32x2_t sv = v * slope;
+    f32x2_t r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r.x) : "v"(v.x), "v"(sv.x));
+    asm("v_max_f32 %0, %1, %2" : "=v"(r.y) : "v"(v.y), "v"(sv.y));
+    return r;
+}
+
+template <typename T>
+struct Half16;
+template <>
+struct Half16<BF16T> {
+    static __device__ __forceinline__ unsigned short bits(float v) {
+        return __builtin_bit_cast(unsigned short, (__bf16)v);
+    }
+    static __device__ __forceinline__ float value(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+};
+template <>
+struct Half16<F16T> {
+    static __device__ __forceinline__ unsigned short bits(float v) {
+        return __builtin_bit_cast(unsigned short, (_Float16)v);
+    }
+    static __device__ __forceinline__ float value(unsigned short b) {
+        return (float)__builtin_bit_cast(_Float16, b);
+    }
+};
+
+// splits eight floats into packed 16-bit high parts and packed 16-bit remainders
+template <typename T>
+__device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned short h0 = Half16<T>::bits(v[2 * i]), h1 = Half16<T>::bits(v[2 * i + 1]);
+        const unsigned short l0 = Half16<T>::bits(v[2 * i] - Half16<T>::value(h0));
+        const unsigned short l1 = Half16<T>::bits(v[2 * i + 1] - Half16<T>::value(h1));
+        h[i] = (unsigned)h0 | ((unsigned)h1 << 16);
+        l[i] = (unsigned)l0 | ((unsigned)l1 << 16);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+// ROWS: the patch width is a multiple of 32, so a 32-voxel group is a piece of one row
+// and its position is decoded once per wave with scalar arithmetic.
+template <typename T, bool ROWS>
+__global__ __launch_bounds__(256) void conv_first16_kernel(
+    const float* __restrict__ xp, const float* __restrict__ w,
+    const float* __restrict__ bias, void* __restrict__ dst, int nvox, int d, int h, int wd,
+    int c0p, float slope) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int half = lane >> 5, r = lane & 31;
+    const int co_tile = blockIdx.y * 32;
+    const int hw = h * wd, dhw = d * hw;
+    const int pw = wd + 2, phw = (h + 2) * pw;   // padded row / plane strides
+
+    // A operands (weights of output channel co_tile + r) and the taps' offsets in the padded patch
+    uint4 whi[2], wlo[2];
+    int rel[2][8];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        float wv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = 8 * (half + 2 * st) + j;
+            const bool real = t < 27;
+            const int tt = real ? t : 0;
+            wv[j] = real ? w[tt * c0p + co_tile + r] : 0.f;   // zero weight for the padding taps
+            rel[st][j] = (tt / 9) * phw + ((tt / 3) % 3) * pw + tt % 3;
+        }
+        split8<T>(wv, whi[st], wlo[st]);
+    }
+    float4 bq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        bq[q] = *reinterpret_cast<const float4*>(bias + co_tile + 8 * q + 4 * half);
+
+    constexpr int G = T::kG;
+    constexpr int ES = 16 / G;
+    constexpr int RECB = 32 * ES;
+    constexpr int RECP = RECB + 16;
+    constexpr int CPT = RECB / 32;
+    __shared__ __attribute__((aligned(16))) char tr[4 * 32 * RECP];
+    char* wl = tr + wave * (32 * RECP);
+
+    // a wave walks 32-voxel groups: the weight operands above are set up once
+    const int ngroups = (nvox + 31) / 32;
+    for (int grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gridDim.x * 4) {
+        int v, nb, sp, zz, yy, xx;
+        if (ROWS) {
+            const int g0 = __builtin_amdgcn_readfirstlane(grp) * 32;   // first voxel of the group
+            nb = g0 / dhw;
+            const int sp0 = g0 - nb * dhw;
+            zz = sp0 / hw;
+            yy = (sp0 - zz * hw) / wd;
+            xx = sp0 - zz * hw - yy * wd + r;
+            sp = sp0 + r;
+            v = g0 + r;
+        } else {
+            v = grp * 32 + r;
+            const int vc = v < nvox ? v : nvox - 1;
+            nb = vc / dhw; sp = vc - nb * dhw;
+            zz = sp / hw; yy = (sp - zz * hw) / wd; xx = sp - zz * hw - yy * wd;
+        }
+        // padded address of tap (0,0,0) = voxel (zz-1, yy-1, xx-1)
+        const float* base = xp + ((size_t)nb * (d + 2) + zz) * phw + yy * pw + xx;
+        f32x16_ct acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc[4 * q + 0] = bq[q].x; acc[4 * q + 1] = bq[q].y;
+            acc[4 * q + 2] = bq[q].z; acc[4 * q + 3] = bq[q].w;
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            float xv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[j] = base[rel[st][j]];
+            uint4 xhi, xlo;
+            split8<T>(xv, xhi, xlo);
+            mma_ct<T>(acc, whi[st], xhi);
+            mma_ct<T>(acc, whi[st], xlo);
+            mma_ct<T>(acc, wlo[st], xhi);
+        }
+        // LeakyReLU, then through LDS so that each store instruction writes the 32 voxel
+        // records of one chunk plane
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cl = 8 * q + 4 * half;
+            const f32x2_t a0 = leaky2((f32x2_t){acc[4 * q], acc[4 * q + 1]}, slope);
+            const f32x2_t a1 = leaky2((f32x2_t){acc[4 * q + 2], acc[4 * q + 3]}, slope);
+            const float o8[8] = {a0.x, a0.y, a1.x, a1.y, 0.f, 0.f, 0.f, 0.f};
+            const uint4 pk = T::pack(o8);
+            *reinterpret_cast<uint2*>(wl + r * RECP + cl * ES) = make_uint2(pk.x, pk.y);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int vv = lane >> 1, sub = lane & 1;
+        int vo, nbo, spo;
+        if (ROWS) {
+            vo = v - r + vv; nbo = nb; spo = sp - r + vv;
+        } else {
+            vo = grp * 32 + vv;
+            const int voc = vo < nvox ? vo : nvox - 1;
+            nbo = voc / dhw; spo = voc - nbo * dhw;
+        }
+        char* const dplane = static_cast<char*>(dst) +
+                             ((size_t)nbo * (c0p * ES / 32) + blockIdx.y * CPT) * dhw * 32;
+#pragma unroll
+        for (int ck = 0; ck < CPT; ++ck) {
+            const uint4 val = *reinterpret_cast<const uint4*>(wl + vv * RECP + (ck * 2 + sub) * 16);
+            if (vo < nvox)
+                *reinterpret_cast<uint4*>(dplane + ((size_t)ck * dhw + spo) * 32 + sub * 16) = val;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---- max-pool 2x2x2 ----------------------------------------------------------
 // Grid: x = (volume, output plane), y = blocks of 16-byte pieces of that plane, so
 // small pyramid levels still fill their blocks. Index arithmetic is 32-bit; the
@@ -445,7 +615,27 @@ int launch_conv_first(int dtype, const float* x, float* xpad, const float* w, co
     pad_input_kernel<<<pgrid, 128, 0, stream>>>(x, xpad, d, h, wd);
     EXA_CHECK_HIP(hipGetLastError());
     dim3 grid((unsigned)blocks, c0p / 32);
-    DISPATCH_T(dtype, (conv_first_kernel<T, MT><<<grid, 256, 0, stream>>>(xpad, w, bias, dst, (int)nvox, d, h, wd, c0p, slope)));
+    // the 16-bit kernel's waves walk the 32-voxel groups: 8 workgroups per CU are plenty
+    const size_t groups = (nvox + 31) / 32;
+    dim3 grid16((unsigned)(groups / 4 < 2048 ? (groups + 3) / 4 : 2048), c0p / 32);
+    switch (dtype) {
+        case EXASPIM_DT_F32:
+            conv_first_kernel<F32T, MT><<<grid, 256, 0, stream>>>(xpad, w, bias, dst, (int)nvox, d, h, wd, c0p, slope);
+            break;
+        case EXASPIM_DT_BF16:
+            if (wd % 32 == 0)
+                conv_first16_kernel<BF16T, true><<<grid16, 256, 0, stream>>>(xpad, w, bias, dst, (int)nvox, d, h, wd, c0p, slope);
+            else
+                conv_first16_kernel<BF16T, false><<<grid16, 256, 0, stream>>>(xpad, w, bias, dst, (int)nvox, d, h, wd, c0p, slope);
+            break;
+        case EXASPIM_DT_F16:
+            if (wd % 32 == 0)
+                conv_first16_kernel<F16T, true><<<grid16, 256, 0, stream>>>(xpad, w, bias, dst, (int)nvox, d, h, wd, c0p, slope);
+            else
+                conv_first16_kernel<F16T, false><<<grid16, 256, 0, stream>>>(xpad, w, bias, dst, (int)nvox, d, h, wd, c0p, slope);
+            break;
+        default: set_error("unknown dtype %d", dtype); return EXASPIM_E_INVALID;
+    }
     EXA_CHECK_HIP(hipGetLastError());
     return EXASPIM_OK;
 }
