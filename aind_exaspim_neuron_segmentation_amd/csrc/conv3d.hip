@@ -847,12 +847,16 @@ static int launch_typed(const ConvArgs& a, hipStream_t stream) {
         return launch_cfg<Tag, 4, 4, 24, 4, 1, 3, 1, 2>(a, stream);
     }
     if (a.w > 6) {
+        // 256 couts and more: 32-cout slices on two-wave workgroups fill the 256 CUs better
+        // than 128-cout slices (144 tiles per batch of 16 at the 12^3 level)
+        if (a.cout % 256 == 0) return launch_cfg<Tag, 4, 4, 12, 2, 1, 3, 1, 2>(a, stream);
         if (a.cout % 128 == 0) return launch_cfg<Tag, 4, 4, 12, 2, 2, 3, 2, 2>(a, stream);
         if (a.cout % 64 == 0) return launch_cfg<Tag, 4, 4, 12, 2, 2, 3, 1, 2>(a, stream);
         return launch_cfg<Tag, 4, 4, 12, 2, 1, 3, 1, 2>(a, stream);
     }
-    if (a.cout % 64 == 0) return launch_cfg<Tag, 6, 6, 6, 2, 2, 4, 1, 2>(a, stream);
-    return launch_cfg<Tag, 6, 6, 6, 2, 1, 4, 1, 2>(a, stream);
+    // 6^3 level: the whole patch is one tile; 32-cout slices on four waves give the most
+    // workgroups (16 patches x 8 slices for 256 couts)
+    return launch_cfg<Tag, 6, 6, 6, 4, 1, 2, 1, 2>(a, stream);
 }
 
 bool conv_can_fuse_head(int cout, int w, int head_oc) {

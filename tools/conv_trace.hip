@@ -26,7 +26,10 @@ int main(int argc, char** argv) {
     const int edge = atoi(argv[4]), n = atoi(argv[5]);
     const size_t vox = (size_t)n * edge * edge * edge;
     const int cin = ca + cb, nchunks = cin / 16, ntiles = cout / 32;
-    std::vector<uint16_t> h((size_t)vox * (ca > cb ? ca : cb));
+    const size_t wbytes = (size_t)nchunks * 27 * ntiles * 1024;
+    size_t helems = (size_t)vox * (ca > cb ? ca : cb);
+    if (helems < wbytes / 2) helems = wbytes / 2;   // the same host buffer seeds the weights
+    std::vector<uint16_t> h(helems);
     uint64_t s = 88172645463325252ull;
     for (auto& v : h) {
         s ^= s << 13; s ^= s >> 7; s ^= s << 17;
@@ -40,13 +43,12 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&b_dev, vox * cb * 2));
         CK(hipMemcpy(b_dev, h.data(), vox * cb * 2, hipMemcpyHostToDevice));
     }
-    const size_t wbytes = (size_t)nchunks * 27 * ntiles * 1024;
     CK(hipMalloc(&w_dev, wbytes));
     CK(hipMemcpy(w_dev, h.data(), wbytes, hipMemcpyHostToDevice));
     CK(hipMalloc(&bias, cout * 4));
     CK(hipMemset(bias, 0, cout * 4));
     CK(hipMalloc(&dst, vox * cout * 2));
-    const size_t nwg = (size_t)n * ((edge + 5) / 6) * (edge / 8) * (edge / 16);   // tiles
+    const size_t nwg = (size_t)n * ((edge + 5) / 6) * ((edge + 7) / 8) * ((edge + 15) / 16) + 64;   // tiles (upper bound)
     unsigned long long* trace;
     const size_t tbytes = nwg * 4 * 16 * 8;
     CK(hipMalloc(&trace, tbytes));
