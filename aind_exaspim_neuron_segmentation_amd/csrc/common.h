@@ -111,6 +111,10 @@ struct ConvArgs {
     // the caller (predict() trims them, inference.py:161-162): kernels that can
     // skip them do (the z-column kernel drops whole tiles), the others ignore it.
     int margin = 0;
+    // Optional fused MaxPool3d(2) (unet3d.py:195) of this conv's output, written to
+    // pool_dst as (n, cout, d/2, h/2, w/2) in the same layout (z-column kernel only:
+    // ask conv_can_fuse_pool first); saves re-reading the whole skip tensor.
+    void* pool_dst = nullptr;
 #ifdef EXASPIM_TRACE
     // tools/conv_trace.hip only: 16 x 64-bit cycle stamps per wave (never in the library build)
     unsigned long long* trace = nullptr;
@@ -119,6 +123,7 @@ struct ConvArgs {
 
 int launch_conv3x3x3(int dtype, const ConvArgs& a, hipStream_t stream);
 bool conv_can_fuse_head(int cout, int w, int head_oc);
+bool conv_can_fuse_pool(int cout, int d, int h, int w);
 
 // xpad: scratch for the zero-bordered copy of x, n * (d+2)(h+2)(wd+2) floats
 int launch_conv_first(int dtype, const float* x, float* xpad, const float* w, const float* bias,

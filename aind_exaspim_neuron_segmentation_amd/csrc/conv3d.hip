@@ -80,6 +80,37 @@ __device__ __forceinline__ float leaky(float v, float slope) {
     return r;
 }
 
+// element-wise maximum of two 16-byte channel groups in the storage type (exact: the
+// inputs are already rounded, the larger one is returned bit for bit)
+template <typename Tag>
+__device__ __forceinline__ uint4 max16(const uint4& a, const uint4& b);
+template <>
+__device__ __forceinline__ uint4 max16<F32Tag>(const uint4& a, const uint4& b) {
+    return make_uint4(__float_as_uint(fmaxf(__uint_as_float(a.x), __uint_as_float(b.x))),
+                      __float_as_uint(fmaxf(__uint_as_float(a.y), __uint_as_float(b.y))),
+                      __float_as_uint(fmaxf(__uint_as_float(a.z), __uint_as_float(b.z))),
+                      __float_as_uint(fmaxf(__uint_as_float(a.w), __uint_as_float(b.w))));
+}
+__device__ __forceinline__ unsigned max_bf16x2(unsigned a, unsigned b) {
+    const float lo = fmaxf(__uint_as_float(a << 16), __uint_as_float(b << 16));
+    const float hi = fmaxf(__uint_as_float(a & 0xffff0000u), __uint_as_float(b & 0xffff0000u));
+    return (__float_as_uint(hi) & 0xffff0000u) | (__float_as_uint(lo) >> 16);
+}
+template <>
+__device__ __forceinline__ uint4 max16<BF16Tag>(const uint4& a, const uint4& b) {
+    return make_uint4(max_bf16x2(a.x, b.x), max_bf16x2(a.y, b.y), max_bf16x2(a.z, b.z), max_bf16x2(a.w, b.w));
+}
+__device__ __forceinline__ unsigned max_f16x2(unsigned a, unsigned b) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 x = __builtin_bit_cast(h2, a), y = __builtin_bit_cast(h2, b);
+    const h2 m = {x.x > y.x ? x.x : y.x, x.y > y.y ? x.y : y.y};
+    return __builtin_bit_cast(unsigned, m);
+}
+template <>
+__device__ __forceinline__ uint4 max16<F16Tag>(const uint4& a, const uint4& b) {
+    return make_uint4(max_f16x2(a.x, b.x), max_f16x2(a.y, b.y), max_f16x2(a.z, b.z), max_f16x2(a.w, b.w));
+}
+
 // 16-byte buffer load with hardware range check: an offset at or beyond the
 // descriptor's size returns zeros, which is how the conv's zero padding (and
 // the tail of the staging list) is produced without branches.
@@ -362,7 +393,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
 //    layout a load instruction covers whole halo rows of contiguous bytes (the
 //    texture addresser works per 64-byte segment: 16 cycles per instruction
 //    instead of 64 with one voxel record per lane).
-template <typename Tag, int TZ, int TY, int TX, int MINW, int D, int HEAD = 0>
+template <typename Tag, int TZ, int TY, int TX, int MINW, int D, int HEAD = 0, bool POOL = false>
 __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
     ConvArgs a, int tiles_z, int tiles_y, int tiles_x) {
     constexpr int G = Tag::kG;
@@ -685,7 +716,10 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
             // once, so the LDS round trips and the stores of a batch overlap.
             constexpr int CPT = RECB / 32;                       // chunk planes of a 32-cout slice
             constexpr int TB_MAX = LDS_UNITS * 16 / (NWAVES * 32 * RECP);
-            constexpr int TB = TB_MAX >= TZ ? TZ : (TB_MAX >= (TZ + 1) / 2 ? (TZ + 1) / 2 : 1);
+            // with the fused max-pool a batch must hold whole pairs of planes
+            constexpr int TB = POOL ? ((TB_MAX >= TZ ? TZ : TB_MAX) & ~1)
+                                    : (TB_MAX >= TZ ? TZ : (TB_MAX >= (TZ + 1) / 2 ? (TZ + 1) / 2 : 1));
+            static_assert(!POOL || (TB >= 2 && TZ % 2 == 0 && TY % 2 == 0 && TX == 16), "pooled tile shape");
             char* wl = reinterpret_cast<char*>(lds) + wave * (TB * 32 * RECP);
             char* const dplane = static_cast<char*>(a.dst) +
                                  ((size_t)cur.nb * (a.cout / KC) + ntile0 * CPT) * patch_vox * 32;
@@ -724,6 +758,35 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
                             *reinterpret_cast<uint4*>(dplane + ((size_t)ck * patch_vox + vox) * 32 + sub * 16) = val;
                     }
                 }
+                if (POOL) {
+                    // MaxPool3d(2) of the planes in LDS: the wave's 2 rows x 16 voxels x TB planes
+                    // give TB/2 x 8 pooled voxels; a piece is one 16-byte group of one of them,
+                    // the maximum over its 2 x 2 x 2 source records (record = row * 16 + x).
+                    constexpr int NP = (TB / 2) * 8 * CPT * 2;
+                    const int pd = a.d >> 1, ph = a.h >> 1, pw2 = a.w >> 1;
+                    const size_t pvox = (size_t)pd * ph * pw2;
+                    char* const pplane = static_cast<char*>(a.pool_dst) +
+                                         ((size_t)cur.nb * (a.cout / KC) + ntile0 * CPT) * pvox * 32;
+#pragma unroll
+                    for (int p0 = 0; p0 < NP; p0 += 64) {
+                        const int p = p0 + lane;
+                        const int zp = p / (8 * CPT * 2), rem = p % (8 * CPT * 2);
+                        const int ck = rem / 16, xp = (rem % 16) >> 1, sb = rem & 1;
+                        if (p < NP && zb + 2 * zp + 1 < TZ) {
+                            const char* rec = wl + (2 * zp) * (32 * RECP) + (2 * xp) * RECP + (ck * 2 + sb) * 16;
+                            uint4 m = *reinterpret_cast<const uint4*>(rec);
+#pragma unroll
+                            for (int k = 1; k < 8; ++k)
+                                m = max16<Tag>(m, *reinterpret_cast<const uint4*>(
+                                                      rec + (k >> 2) * (32 * RECP) + ((k >> 1) & 1) * 16 * RECP +
+                                                      (k & 1) * RECP));
+                            const int qz = (cur.z0 + zb) / 2 + zp, qy = cur.y0 / 2 + wave, qx = cur.x0 / 2 + xp;
+                            if (qz < pd && qy < ph && qx < pw2)
+                                *reinterpret_cast<uint4*>(pplane + ((size_t)ck * pvox +
+                                                                    ((size_t)qz * ph + qy) * pw2 + qx) * 32 + sb * 16) = m;
+                        }
+                    }
+                }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
@@ -754,7 +817,7 @@ static int resident_workgroups(int per_cu) {
     return cus * per_cu;
 }
 
-template <typename Tag, int TZ, int TY, int TX, int MINW, int D, int HEAD = 0>
+template <typename Tag, int TZ, int TY, int TX, int MINW, int D, int HEAD = 0, bool POOL = false>
 static int launch_zpipe(const ConvArgs& a, hipStream_t stream) {
     // tiles cover the voxels the caller needs, [margin, size - margin) on every axis
     const int m2 = 2 * a.margin;
@@ -774,7 +837,7 @@ static int launch_zpipe(const ConvArgs& a, hipStream_t stream) {
     if (g_variant >= 10 && g_variant < 20) wgs = blocks;
 #endif
     dim3 grid((unsigned)wgs, slices);
-    conv3x3x3_zpipe<Tag, TZ, TY, TX, MINW, D, HEAD><<<grid, TY * TX * 2, 0, stream>>>(a, tz, ty, tx);
+    conv3x3x3_zpipe<Tag, TZ, TY, TX, MINW, D, HEAD, POOL><<<grid, TY * TX * 2, 0, stream>>>(a, tz, ty, tx);
     EXA_CHECK_HIP(hipGetLastError());
     return EXASPIM_OK;
 }
@@ -814,6 +877,7 @@ static int launch_zpipe_head(const ConvArgs& a, hipStream_t stream) {
             case 4: return launch_zpipe<Tag, TZ, 8, 16, 2, D, 4>(a, stream);
         }
     }
+    if (a.pool_dst) return launch_zpipe<Tag, TZ, 8, 16, 2, D, 0, true>(a, stream);
     return launch_zpipe<Tag, TZ, 8, 16, 2, D>(a, stream);
 }
 
@@ -859,6 +923,11 @@ static int launch_typed(const ConvArgs& a, hipStream_t stream) {
     return launch_cfg<Tag, 6, 6, 6, 4, 1, 2, 1, 2>(a, stream);
 }
 
+bool conv_can_fuse_pool(int cout, int d, int h, int w) {
+    // the layers launch_typed sends to the z-column kernel, on even patch sizes
+    return cout % 64 != 0 && w >= 16 && w % 16 == 0 && d % 2 == 0 && h % 2 == 0;
+}
+
 bool conv_can_fuse_head(int cout, int w, int head_oc) {
     return cout == 32 && w >= 16 && w % 16 == 0 && head_oc >= 1 && head_oc <= 4;
 }
@@ -871,6 +940,8 @@ int launch_conv3x3x3(int dtype, const ConvArgs& a, hipStream_t stream) {
     EXA_CHECK_ARG(a.slope >= 0.f && a.slope <= 1.f, "conv: LeakyReLU slope %g outside [0, 1]", a.slope);
     EXA_CHECK_ARG(a.margin >= 0 && 2 * a.margin < a.d && 2 * a.margin < a.h && 2 * a.margin < a.w,
                   "conv: margin %d leaves nothing of a %dx%dx%d patch", a.margin, a.d, a.h, a.w);
+    EXA_CHECK_ARG(!a.pool_dst || (conv_can_fuse_pool(a.cout, a.d, a.h, a.w) && !a.head_out && a.margin == 0),
+                  "conv: fused max-pool needs a 32-cout-slice layer on an even, untrimmed patch");
     EXA_CHECK_ARG(!a.head_out || conv_can_fuse_head(a.cout, a.w, a.head_oc),
                   "conv: fused head needs cout 32, w %% 16 == 0, 1..4 outputs");
     {   // the LDS-DMA staging addresses one patch of one source with 32-bit offsets

@@ -101,9 +101,12 @@ static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, in
     // With the head fused, voxels within "trim" of a patch face are never read again:
     // up4.3 skips them, and up4.0 everything its 3x3x3 consumer does not reach.
     const bool trimmed = fuse_head && trim > 0 && 2 * trim < d && 2 * trim < h && 2 * trim < w;
+    const bool fuse_pool = conv_can_fuse_pool(p.conv[0].cout, d, h, w);
     auto conv = [&](int idx, const void* sa, const void* sb, void* dst, int l) -> int {
         const ConvLayer& L = p.conv[idx];
         ConvArgs a;
+        // inc.3 can write its own 2x2x2 max-pool (the input of down1) next to its output
+        if (idx == 0 && fuse_pool) a.pool_dst = A(1);
         if (trimmed && idx == kNumMfmaConvs - 1) a.margin = trim;
         if (trimmed && idx == kNumMfmaConvs - 2) a.margin = trim - 1;
         if (idx == kNumMfmaConvs - 1 && fuse_head) {
@@ -146,8 +149,9 @@ static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, in
     for (int l = 1; l <= 4; ++l) {
         const ConvLayer& L0 = p.conv[2 * l - 1];
         const void* prev = skip(l - 1);
-        RUN(launch_maxpool2(dt, prev, A(l), n, d >> (l - 1), h >> (l - 1), w >> (l - 1), L0.ca,
-                            stream));
+        if (!(l == 1 && fuse_pool))
+            RUN(launch_maxpool2(dt, prev, A(l), n, d >> (l - 1), h >> (l - 1), w >> (l - 1), L0.ca,
+                                stream));
         RUN(conv(2 * l - 1, A(l), nullptr, B(l), l));
         RUN(conv(2 * l, B(l), nullptr, l < 4 ? skip(l) : A(l), l));  // x2..x4, x5 in A(4)
     }
