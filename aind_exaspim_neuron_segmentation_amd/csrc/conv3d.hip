@@ -145,6 +145,20 @@ __device__ __forceinline__ void store4<F16Tag>(void* dst, size_t off, float a, f
     *reinterpret_cast<f16x4*>(static_cast<_Float16*>(dst) + off) = v;
 }
 
+// Phase stamps for tools/conv_trace.hip (compiled out of the library).
+#ifndef EXASPIM_ABLATE
+#define EXASPIM_ABLATE 0   // tools only: 1 = no prefetch loads, 2 = no output stores, 4 = no LDS staging writes
+#endif
+#ifdef EXASPIM_TRACE
+#define EXA_TRACE(ev)                                                                          \
+    do {                                                                                       \
+        if (a.trace && lane == 0)                                                              \
+            a.trace[trace_rec + (ev)] = __builtin_readcyclecounter();                          \
+    } while (0)
+#else
+#define EXA_TRACE(ev) do { } while (0)
+#endif
+
 // ---- conv3x3x3_t14: register-staged prefetch (async-STAGE split), deeper operand
 // pipelining and an LDS-transposed epilogue -------------------------------------
 // Same tiling and LDS image as above. Differences:
@@ -268,9 +282,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
         }
     };
 
+#ifdef EXASPIM_TRACE
+    const size_t trace_rec = ((size_t)blockIdx.x * NWAVES + wave) * 16;
+    if (a.trace && lane == 0)
+        a.trace[trace_rec + 15] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                                  (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
+    EXA_TRACE(0);
     stage_load(0);
+    EXA_TRACE(1);
     stage_store();
     __syncthreads();
+    EXA_TRACE(2);
 
     for (int c = 0; c < nchunks; ++c) {
         const uint4* wp = static_cast<const uint4*>(a.weights) +
@@ -308,10 +331,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
             // this fence hipcc hoists and sinks them across taps and the loop runs ~20 % slower
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (c < 4) EXA_TRACE(3 + 3 * c);
         __syncthreads();  // every wave is done reading this chunk's image
+        if (c < 4) EXA_TRACE(4 + 3 * c);
         if (more) {
             stage_store();
             __syncthreads();
+            if (c < 3) EXA_TRACE(5 + 3 * c);
         }
     }
 
@@ -355,21 +381,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    EXA_TRACE(14);
 }
-
-// Phase stamps for tools/conv_trace.hip (compiled out of the library).
-#ifndef EXASPIM_ABLATE
-#define EXASPIM_ABLATE 0   // tools only: 1 = no prefetch loads, 2 = no output stores, 4 = no LDS staging writes
-#endif
-#ifdef EXASPIM_TRACE
-#define EXA_TRACE(ev)                                                                          \
-    do {                                                                                       \
-        if (a.trace && lane == 0)                                                              \
-            a.trace[trace_rec + (ev)] = __builtin_readcyclecounter();                          \
-    } while (0)
-#else
-#define EXA_TRACE(ev) do { } while (0)
-#endif
 
 // ---- conv3x3x3_zpipe: z-column tiles for the 32-cout slices ----------------------------
 // A wave owns one 32-voxel (y, x) group of the tile times all TZ planes (TZ

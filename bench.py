@@ -42,9 +42,10 @@ from aind_exaspim_neuron_segmentation_amd.utils import synthetic  # noqa: E402
 
 FLOP_PER_PATCH_96 = 370_145_230_848  # 2 x MAC over the 19 convs
 PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense MFMA, MI355X_MICROARCH.md
-# Launches of the dominant kernel symbol, conv3x3x3_zpipe<.., 6, 8, 16, 2, 4, HEAD = 0>
-# (32-cout layers without the fused head): (bit in the timing mask, Cin, Cout, edge)
-DOMINANT_CONVS = [(0, 32, 32, 96), (14, 64, 32, 48), (15, 64, 32, 96)]  # inc.3, up3.3, up4.0
+# Launches of the dominant kernel symbol, conv3x3x3_zpipe<.., 6, 8, 16, 2, 4, HEAD = 0, POOL = false>
+# (32-cout decoder layers without the fused head; inc.3 is the POOL = true instantiation):
+# (bit in the timing mask, Cin, Cout, edge)
+DOMINANT_CONVS = [(14, 64, 32, 48), (15, 64, 32, 96)]  # up3.3, up4.0
 TRIM = 8  # predict()'s default (inference.py:38)
 
 
@@ -178,9 +179,9 @@ def main():
     if rank == 0:
         total_vox = float(gshape[0]) * gshape[1] * gshape[2]
         value = total_vox * args.steps / elapsed
-        # roofline of the dominant kernel symbol (the 32-cout MFMA convolution: inc.3,
-        # up3.3 and up4.0 are the same instantiation, so rocprofv3's per-kernel
-        # average covers exactly these launches)
+        # roofline of the dominant kernel symbol (the 32-cout MFMA convolution: up3.3 and
+        # up4.0 are the same instantiation, so rocprofv3's per-kernel average covers
+        # exactly these launches)
         launches = sum(cnt[b] for b, _, _, _ in DOMINANT_CONVS)
         k_ms = sum(ms[b] for b, _, _, _ in DOMINANT_CONVS)
         flops = 0.0
@@ -204,7 +205,7 @@ def main():
             with open(tpath) as f:
                 kernels = json.load(f).get("kernels", {})
             tag = {"bf16": "BF16Tag", "fp16": "F16Tag", "fp32": "F32Tag"}[args.dtype]
-            entry = kernels.get(f"conv3x3x3_zpipe<{tag}, 6, 8, 16, 2, 4, 0>")
+            entry = kernels.get(f"conv3x3x3_zpipe<{tag}, 6, 8, 16, 2, 4, 0, false>")
             if entry:
                 traffic = entry["hbm_bytes_per_launch"]
         result = {
@@ -233,7 +234,7 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "conv3x3x3_zpipe<tile 6x8x16, 32 couts, no head> (launches: inc.3, up3.3, up4.0)",
+                "kernel": "conv3x3x3_zpipe<tile 6x8x16, 32 couts, no head, no pool> (launches: up3.3, up4.0)",
                 "algorithmic_flop_per_launch": flops / launches if launches else None,
                 "achieved": achieved,
                 "peak": peak,

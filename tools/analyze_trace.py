@@ -7,6 +7,7 @@ import numpy as np
 
 def main(path, ms=None):
     t = np.fromfile(path, dtype=np.uint64).reshape(-1, 4, 16).astype(np.int64)
+    t = t[t[:, 0, 14] > 0]   # records of workgroups / tiles that ran
     nwg = t.shape[0]
     hw = t[:, :, 15]
     xcc = (hw >> 32) & 0xF

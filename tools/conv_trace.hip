@@ -48,7 +48,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&bias, cout * 4));
     CK(hipMemset(bias, 0, cout * 4));
     CK(hipMalloc(&dst, vox * cout * 2));
-    const size_t nwg = (size_t)n * ((edge + 5) / 6) * ((edge + 7) / 8) * ((edge + 15) / 16) + 64;   // tiles (upper bound)
+    const size_t nwg = (size_t)n * ((edge + 3) / 4) * ((edge + 3) / 4) * ((edge + 11) / 12) + 64;   // tiles (upper bound over the tile shapes)
     unsigned long long* trace;
     const size_t tbytes = nwg * 4 * 16 * 8;
     CK(hipMalloc(&trace, tbytes));
