@@ -151,6 +151,31 @@ def test_trimmed_forward_is_bit_identical_inside(dev, oracle, cdt, shape, trim):
     assert bool((part[..., 0, :, :] == -7.0).all()) and bool((part[..., :, :, -1] == -7.0).all())
 
 
+def test_trimmed_forward_variants(dev, oracle):
+    """Trim on the ConvTranspose variant and on fp16, a batch that does not fill the
+    persistent grid evenly, and a trim that would leave nothing (= full forward)."""
+    model, _ = make_model(dev, seed=8, compute_dtype="fp16", trilinear=False)
+    x = normalized_input(oracle, (32, 32, 48), seed=71, n=5).to(dev)
+    full = model.run(x, apply_sigmoid=True)
+    part = model.run(x, apply_sigmoid=True, trim=6)
+    assert torch.equal(part[..., 6:-6, 6:-6, 6:-6], full[..., 6:-6, 6:-6, 6:-6])
+    small = normalized_input(oracle, (16, 16, 16), seed=72, n=1).to(dev)
+    assert torch.equal(model.run(small, trim=8), model.run(small))
+    with pytest.raises(ValueError, match="negative trim"):
+        model.run(small, trim=-1)
+
+
+def test_fused_pool_matches_oracle_stages(dev, oracle, golden):
+    """inc.3 writes its own max-pool: the full-width 96^3 golden (per-stage features of the
+    reference) pins everything downstream of it; here a ragged batch at small sizes."""
+    model, sd = make_model(dev, seed=3)
+    for shape, n in (((16, 32, 16), 3), ((48, 16, 32), 1)):
+        x = normalized_input(oracle, shape, seed=73, n=n)
+        want = oracle.unet_forward(x, oracle.OracleModel(sd).sd).numpy()
+        got = model(x.to(dev)).cpu().numpy()
+        assert np.abs(got - want).max() < 1e-4
+
+
 def test_unet_rejects_bad_inputs(dev):
     model, _ = make_model(dev)
     with pytest.raises(RuntimeError, match="Sizes of tensors must match"):
