@@ -18,8 +18,9 @@
  *    caller's HIP stream ("stream", a hipStream_t passed as void*; NULL = the
  *    default stream).
  *  - Volumes are C-ordered (z, y, x). Activations handed across the ABI are
- *    NCDHW float32, like the reference's tensors; the channels-last 16-byte
- *    grouped layout used between kernels is internal to the workspace.
+ *    NCDHW float32, like the reference's tensors; the blocked channels-last
+ *    layout used between kernels (one plane of 32-byte voxel records per
+ *    32-byte channel chunk) is internal to the workspace.
  */
 #ifndef EXASPIM_AFFINITY_H
 #define EXASPIM_AFFINITY_H
