@@ -176,6 +176,24 @@ def test_fused_pool_matches_oracle_stages(dev, oracle, golden):
         assert np.abs(got - want).max() < 1e-4
 
 
+@pytest.mark.parametrize("wm,shape,n", [(3, (16, 16, 32), 1), (0.25, (32, 16, 16), 2), (1, (16, 16, 16), 33)])
+def test_width_multipliers_and_large_batches(dev, oracle, wm, shape, n):
+    """96-channel level 0 (three 32-cout slices per tile in the z-column kernel, no fused
+    head or pool), heavily padded narrow networks, and a batch beyond the benchmark's."""
+    from aind_exaspim_neuron_segmentation_amd.machine_learning.unet3d import UNet3D
+
+    sd = synthetic.synth_state_dict(2, wm, seed=11)
+    model = UNet3D(output_channels=2, width_multiplier=wm)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    model = model.to(dev).eval()
+    x = normalized_input(oracle, shape, seed=74, n=n)
+    want = oracle.unet_forward(x, oracle.OracleModel(sd).sd).numpy()
+    got = model(x.to(dev)).cpu().numpy()
+    err = np.abs(got - want).max()
+    print(f"width x{wm}, batch {n}: max|diff| = {err:.3e}")
+    assert err < 2e-4 * max(1.0, float(np.abs(want).max()))
+
+
 def test_unet_rejects_bad_inputs(dev):
     model, _ = make_model(dev)
     with pytest.raises(RuntimeError, match="Sizes of tensors must match"):
