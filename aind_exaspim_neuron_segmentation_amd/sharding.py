@@ -292,7 +292,8 @@ def exchange_input_halo(core, shard, group):
 
 
 def predict_shard(volume, model, plan, shard, n_channels=3, batch_size=16,
-                  brightness_clip=1000, normalization_percentiles=(1, 99.9), group=None):
+                  brightness_clip=1000, normalization_percentiles=(1, 99.9), group=None,
+                  n_streams=1):
     """
     Runs one rank's share of predict() on its device: global percentiles
     (histogram all-reduce), the rank's patches, the band exchange and the final
@@ -339,7 +340,7 @@ def predict_shard(volume, model, plan, shard, n_channels=3, batch_size=16,
     accum_block = _native.Block.make(shard.accum_dims, shard.accum_origin, plan.shape)
     accum = inference.run_sliding_window(
         volume, model, plan, n_channels, batch_size, brightness_clip, mn, mx,
-        starts=shard.starts, accum_block=accum_block,
+        starts=shard.starts, accum_block=accum_block, n_streams=n_streams,
     )
     if multi:
         exchange_output_bands(accum, shard, group)

@@ -58,6 +58,9 @@ def parse_args():
     p.add_argument("--size", type=int, default=1024, help="volume edge per GPU")
     p.add_argument("--batch", type=int, default=16)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--streams", type=int, default=1,
+                   help="batches in flight on separate HIP streams (default 1: kernels never share "
+                        "the device, so the per-kernel roofline timing means what it says)")
     p.add_argument("--cpu-sample", type=int, default=160, help="edge of the CPU sample volume")
     return p.parse_args()
 
@@ -136,6 +139,7 @@ def main():
         return sharding.predict_shard(
             volume, model, plan, shard, n_channels=3, batch_size=args.batch,
             brightness_clip=1000, normalization_percentiles=(1, 99.9), group=group,
+            n_streams=args.streams,
         )
 
     def barrier():
@@ -231,6 +235,7 @@ def main():
                             "exchanged between neighbours" if world > 1 else "single device",
                 "tflops_end_to_end": value * FLOP_PER_PATCH_96 / 64 ** 3 / 1e12,
                 "output_checksum": checksum,
+                "streams": args.streams,
             },
             "roofline": {
                 "bound": "mfma",
