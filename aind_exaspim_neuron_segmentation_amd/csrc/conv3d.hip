@@ -957,7 +957,7 @@ int launch_conv3x3x3(int dtype, const ConvArgs& a, hipStream_t stream) {
                   "conv: fused max-pool needs a 32-cout-slice layer on an even, untrimmed patch");
     EXA_CHECK_ARG(!a.head_out || conv_can_fuse_head(a.cout, a.w, a.head_oc),
                   "conv: fused head needs cout 32, w %% 16 == 0, 1..4 outputs");
-    {   // the LDS-DMA staging addresses one patch of one source with 32-bit offsets
+    {   // the staging loads address one patch of one source with 32-bit buffer offsets
         const unsigned long long rec = (unsigned long long)a.d * a.h * a.w *
                                        (a.ca > a.cb ? a.ca : a.cb) * (dtype == EXASPIM_DT_F32 ? 4 : 2);
         EXA_CHECK_ARG(rec < 0x80000000ULL, "conv: one patch of one source is %llu bytes (>= 2 GiB)", rec);

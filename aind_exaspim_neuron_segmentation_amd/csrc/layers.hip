@@ -1,7 +1,9 @@
 // The layers of the U-Net around the 3x3x3 convolutions, on the blocked
 // channels-last layout of conv3d.hip, (N, C / chunk, D, H, W, 32 B):
 //   conv_first : inc.0, Conv3d(1 -> C0, k3, p1) + folded BN + LeakyReLU
-//                (machine_learning/unet3d.py:64,143-145) from the float32 patch
+//                (machine_learning/unet3d.py:64,143-145) from the float32 patch;
+//                exact fp32 MFMA in fp32 mode, split 16-bit operands otherwise
+//   convt2     : nn.ConvTranspose3d(k=2, s=2) of UNet3D(trilinear=False) (unet3d.py:254)
 //   maxpool2   : nn.MaxPool3d(2)                          (unet3d.py:195)
 //   upsample2  : nn.Upsample(x2, trilinear, align_corners=True) (unet3d.py:248)
 //   head       : OutConv 1x1x1 (+ sigmoid of inference.py:158) -> NCDHW float32
