@@ -377,6 +377,18 @@ def test_predict_input_variants(dev, oracle):
         inference.predict(vol, model, patch_shape=(24, 32, 32), overlap=(8, 8, 8), verbose=False)
 
 
+def test_predict_streams_do_not_change_the_result(dev):
+    """predict(n_streams=k): batches in flight on k HIP streams, stitched in batch order."""
+    from aind_exaspim_neuron_segmentation_amd import inference
+
+    model, _ = make_model(dev, compute_dtype="bf16")
+    vol = synthetic.synth_volume((72, 88, 104), seed=21)
+    kw = dict(batch_size=3, patch_shape=(32, 32, 32), overlap=(8, 8, 8), trim=4, verbose=False)
+    one = inference.predict(vol, model, **kw)
+    for k in (2, 3):
+        assert np.array_equal(inference.predict(vol, model, n_streams=k, **kw), one)
+
+
 def test_synth_volume_matches_numpy(dev):
     from aind_exaspim_neuron_segmentation_amd import _native
 
