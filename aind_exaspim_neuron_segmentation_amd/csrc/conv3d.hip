@@ -91,24 +91,31 @@ __device__ __forceinline__ uint4 max16<F32Tag>(const uint4& a, const uint4& b) {
                       __float_as_uint(fmaxf(__uint_as_float(a.z), __uint_as_float(b.z))),
                       __float_as_uint(fmaxf(__uint_as_float(a.w), __uint_as_float(b.w))));
 }
-__device__ __forceinline__ unsigned max_bf16x2(unsigned a, unsigned b) {
-    const float lo = fmaxf(__uint_as_float(a << 16), __uint_as_float(b << 16));
-    const float hi = fmaxf(__uint_as_float(a & 0xffff0000u), __uint_as_float(b & 0xffff0000u));
-    return (__float_as_uint(hi) & 0xffff0000u) | (__float_as_uint(lo) >> 16);
+// bf16 (and f16) order like sign-magnitude integers: flipping the magnitude bits of negative
+// values, x ^ ((x >> 15) & 0x7fff) per 16-bit half, makes them order like two's-complement
+// shorts, so a packed integer maximum picks the larger float; the map is its own inverse.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned key16x2(unsigned x) {
+    const s16x2 m = __builtin_bit_cast(s16x2, x) >> (short)15;   // 0 or -1 per half
+    return x ^ (__builtin_bit_cast(unsigned, m) & 0x7fff7fffu);
+}
+__device__ __forceinline__ unsigned maxkey16x2(unsigned ka, unsigned kb) {
+    return __builtin_bit_cast(
+        unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, ka), __builtin_bit_cast(s16x2, kb)));
+}
+__device__ __forceinline__ uint4 key16(const uint4& v) {
+    return make_uint4(key16x2(v.x), key16x2(v.y), key16x2(v.z), key16x2(v.w));
+}
+__device__ __forceinline__ uint4 maxkey16(const uint4& a, const uint4& b) {
+    return make_uint4(maxkey16x2(a.x, b.x), maxkey16x2(a.y, b.y), maxkey16x2(a.z, b.z), maxkey16x2(a.w, b.w));
 }
 template <>
 __device__ __forceinline__ uint4 max16<BF16Tag>(const uint4& a, const uint4& b) {
-    return make_uint4(max_bf16x2(a.x, b.x), max_bf16x2(a.y, b.y), max_bf16x2(a.z, b.z), max_bf16x2(a.w, b.w));
-}
-__device__ __forceinline__ unsigned max_f16x2(unsigned a, unsigned b) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    const h2 x = __builtin_bit_cast(h2, a), y = __builtin_bit_cast(h2, b);
-    const h2 m = {x.x > y.x ? x.x : y.x, x.y > y.y ? x.y : y.y};
-    return __builtin_bit_cast(unsigned, m);
+    return key16(maxkey16(key16(a), key16(b)));
 }
 template <>
 __device__ __forceinline__ uint4 max16<F16Tag>(const uint4& a, const uint4& b) {
-    return make_uint4(max_f16x2(a.x, b.x), max_f16x2(a.y, b.y), max_f16x2(a.z, b.z), max_f16x2(a.w, b.w));
+    return key16(maxkey16(key16(a), key16(b)));
 }
 
 // 16-byte buffer load with hardware range check: an offset at or beyond the
@@ -796,11 +803,14 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
                         if (p < NP && zb + 2 * zp + 1 < TZ) {
                             const char* rec = wl + (2 * zp) * (32 * RECP) + (2 * xp) * RECP + (ck * 2 + sb) * 16;
                             uint4 m = *reinterpret_cast<const uint4*>(rec);
+                            if (ES == 2) m = key16(m);   // 16-bit types: compare order-preserving keys
 #pragma unroll
-                            for (int k = 1; k < 8; ++k)
-                                m = max16<Tag>(m, *reinterpret_cast<const uint4*>(
-                                                      rec + (k >> 2) * (32 * RECP) + ((k >> 1) & 1) * 16 * RECP +
-                                                      (k & 1) * RECP));
+                            for (int k = 1; k < 8; ++k) {
+                                const uint4 v = *reinterpret_cast<const uint4*>(
+                                    rec + (k >> 2) * (32 * RECP) + ((k >> 1) & 1) * 16 * RECP + (k & 1) * RECP);
+                                m = ES == 2 ? maxkey16(m, key16(v)) : max16<Tag>(m, v);
+                            }
+                            if (ES == 2) m = key16(m);
                             const int qz = (cur.z0 + zb) / 2 + zp, qy = cur.y0 / 2 + wave, qx = cur.x0 / 2 + xp;
                             if (qz < pd && qy < ph && qx < pw2)
                                 *reinterpret_cast<uint4*>(pplane + ((size_t)ck * pvox +
