@@ -194,6 +194,26 @@ def test_width_multipliers_and_large_batches(dev, oracle, wm, shape, n):
     assert err < 2e-4 * max(1.0, float(np.abs(want).max()))
 
 
+def test_model_in_a_validation_loop(dev, oracle):
+    """The trainer's validate_step / forward_pass pattern (train.py:159-222 of the reference:
+    eval mode, no_grad, autocast, model(x), a criterion on the logits, thresholded
+    precision / recall) works with the HIP-backed module as "self.model"."""
+    model, sd = make_model(dev, out_channels=1, seed=5)
+    x = normalized_input(oracle, (32, 32, 32), seed=75, n=3)
+    y = (torch.rand(3, 1, 32, 32, 32) > 0.7).float()
+    criterion = torch.nn.BCEWithLogitsLoss()
+    model.eval()
+    with torch.no_grad(), torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        hat_y = model(x.to("cuda", dtype=torch.float))
+        loss = criterion(hat_y, y.to("cuda", dtype=torch.float))
+    want = oracle.unet_forward(x, oracle.OracleModel(sd).sd)
+    assert hat_y.dtype == torch.float32 and hat_y.shape == want.shape
+    assert abs(float(loss) - float(criterion(want, y))) < 1e-5
+    # binarised predictions (compute_stats, train.py:246-247) agree except at |logit| ~ 0
+    differ = ((hat_y.cpu() > 0) != (want > 0)) & (want.abs() > 1e-4)
+    assert not bool(differ.any())
+
+
 def test_unet_rejects_bad_inputs(dev):
     model, _ = make_model(dev)
     with pytest.raises(RuntimeError, match="Sizes of tensors must match"):
