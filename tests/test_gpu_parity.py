@@ -464,6 +464,32 @@ def test_full_size_512_periodic_property_and_oracle(dev, oracle):
     assert err < 1e-5
 
 
+def test_full_size_1024_bf16_periodic_property(dev):
+    """1024^3, bf16, batch 16 (BASELINE configs[2], the benchmark's workload) through the same
+    size-independent property, checked on the device: a 64-periodic input gives an output that
+    is bit-for-bit 64-periodic wherever only unpadded patches contribute (every such patch
+    sees the same input and the kernels are deterministic), borders behave as in the
+    reference, and the interior equals the 512^3 result of the same model."""
+    from aind_exaspim_neuron_segmentation_amd import inference
+
+    model, _ = make_model(dev, compute_dtype="bf16")
+    big = _periodic_volume(1024)
+    got = inference.predict(big, model, batch_size=16, verbose=False, return_device_tensor=True)
+    assert tuple(got.shape) == (3, 1024, 1024, 1024) and got.dtype == torch.float32
+    a = got[:, 72:904, 72:904, 72:904]          # covered by unpadded patches only ([72, 968))
+    assert torch.equal(a[:, :768], a[:, 64:832])
+    assert torch.equal(a[:, :, :768], a[:, :, 64:832])
+    assert torch.equal(a[:, :, :, :768], a[:, :, :, 64:832])
+    assert not bool(got[:, :8].any()) and not bool(got[:, :, :8].any()) and not bool(got[:, :, :, :8].any())
+    assert bool(got[:, 1023, 500, 500].all())
+    assert bool(torch.isfinite(got[:, ::37, ::41, ::43]).all())
+    cell = got[:, 136:200, 136:200, 136:200].clone()
+    del got, a
+    small = inference.predict(_periodic_volume(512), model, batch_size=16, verbose=False,
+                              return_device_tensor=True)
+    assert torch.equal(small[:, 136:200, 136:200, 136:200], cell)
+
+
 def test_half_width_model_channel_padding(dev, oracle):
     """width_multiplier = 0.5 (16..256 channels): every level is padded to 32
     channels inside the engine; results must not change."""
