@@ -151,6 +151,43 @@ __global__ __launch_bounds__(128) void gather_kernel(const void* __restrict__ vo
     out[(((size_t)p * pz + z) * py + y) * px + x] = r;
 }
 
+// Unsigned integer volumes with a brightness clip take at most clip + 1 distinct values
+// after np.minimum (inference.py:79), so the float64 normalisation is evaluated once per
+// value into an LDS table (the same expression, entry for entry) and a voxel costs one
+// lookup instead of a float64 division. One block = one (patch, z) plane.
+template <typename V>
+__global__ __launch_bounds__(256) void gather_lut_kernel(const V* __restrict__ vol, exaspim_block blk,
+                                                         const int* __restrict__ starts, int pz,
+                                                         int py, int px, int clip, double mn,
+                                                         double denom, float* __restrict__ out) {
+    extern __shared__ float lut[];
+    for (int v = threadIdx.x; v <= clip; v += blockDim.x) {
+        double q = ((double)v - mn) / denom;   // float64, like numpy (img_util.py:527)
+        q = fmin(fmax(q, 0.0), 1.0);           // np.clip(img, 0, 1)
+        lut[v] = (float)q;                     // cast on assignment (inference.py:191)
+    }
+    __syncthreads();
+    const int p = blockIdx.x / pz, z = blockIdx.x - p * pz;
+    const int sz = starts[3 * p], sy = starts[3 * p + 1], sx = starts[3 * p + 2];
+    const int nz = min(sz + pz, blk.global[0]) - sz;
+    const int ny = min(sy + py, blk.global[1]) - sy;
+    const int nx = min(sx + px, blk.global[2]) - sx;
+    const int lz = sz + reflect_index(z, nz) - blk.origin[0];
+    const bool zok = (unsigned)lz < (unsigned)blk.dims[0];
+    float* const oplane = out + ((size_t)p * pz + z) * py * px;
+    for (int i = threadIdx.x; i < py * px; i += blockDim.x) {
+        const int y = i / px, x = i - y * px;
+        const int ly = sy + reflect_index(y, ny) - blk.origin[1];
+        const int lx = sx + reflect_index(x, nx) - blk.origin[2];
+        float r = 0.f;
+        if (zok && (unsigned)ly < (unsigned)blk.dims[1] && (unsigned)lx < (unsigned)blk.dims[2]) {
+            const int v = (int)vol[((size_t)lz * blk.dims[1] + ly) * blk.dims[2] + lx];
+            r = lut[v < clip ? v : clip];
+        }
+        oplane[i] = r;
+    }
+}
+
 // ------------------------------------------------------------------- stitch --
 struct Coverage {
     int lo[3], hi[3];
@@ -371,8 +408,25 @@ extern "C" int exaspim_gather_patches(const void* vol_dev, int32_t vox_dtype,
     EXA_CHECK_ARG(vol_dev && starts_dev && out_dev && patch, "gather: NULL pointer");
     EXA_CHECK_ARG(n > 0 && patch[0] > 0 && patch[1] > 0 && patch[2] > 0, "gather: empty batch");
     EXA_CHECK_ARG((long long)n * patch[0] <= 65535 && patch[1] <= 65535, "gather: grid too large");
-    const dim3 grid((patch[2] + 127) / 128, patch[1], n * patch[0]);
     hipStream_t s = (hipStream_t)stream;
+    // table path: unsigned integers clipped to a small integer maximum
+    if (has_clip && clip >= 0.0 && clip <= 16383.0 && clip == (double)(int)clip &&
+        (vox_dtype == EXASPIM_VOX_U8 || vox_dtype == EXASPIM_VOX_U16)) {
+        const int ci = (int)clip;
+        const size_t lds = ((size_t)ci + 1) * sizeof(float);
+        const unsigned blocks = (unsigned)((long long)n * patch[0]);
+        if (vox_dtype == EXASPIM_VOX_U8)
+            gather_lut_kernel<uint8_t><<<blocks, 256, lds, s>>>(static_cast<const uint8_t*>(vol_dev), *blk,
+                                                               starts_dev, patch[0], patch[1], patch[2], ci,
+                                                               mn, denom, out_dev);
+        else
+            gather_lut_kernel<uint16_t><<<blocks, 256, lds, s>>>(static_cast<const uint16_t*>(vol_dev), *blk,
+                                                                starts_dev, patch[0], patch[1], patch[2], ci,
+                                                                mn, denom, out_dev);
+        EXA_CHECK_HIP(hipGetLastError());
+        return EXASPIM_OK;
+    }
+    const dim3 grid((patch[2] + 127) / 128, patch[1], n * patch[0]);
 #define GATHER(V) gather_kernel<V><<<grid, 128, 0, s>>>(vol_dev, *blk, starts_dev, patch[0], patch[1], patch[2], clip, has_clip, mn, denom, out_dev)
     switch (vox_dtype) {
         case EXASPIM_VOX_U8: GATHER(EXASPIM_VOX_U8); break;
