@@ -80,18 +80,23 @@ struct F16T {
 // whatever the network's storage type: inc.0 adds no input rounding.
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
-// (n, d, h, w) float32 -> (n, d+2, h+2, w+2) with a zero border.
-__global__ __launch_bounds__(128) void pad_input_kernel(const float* __restrict__ x,
+// (n, d, h, w) float32 -> (n, d+2, h+2, w+2) with a zero border. One block per padded plane.
+__global__ __launch_bounds__(256) void pad_input_kernel(const float* __restrict__ x,
                                                         float* __restrict__ xp, int d, int h, int w) {
-    const int px = blockIdx.x * blockDim.x + threadIdx.x;
-    if (px >= w + 2) return;
-    const int py = blockIdx.y;
-    const int nb = blockIdx.z / (d + 2), pz = blockIdx.z - nb * (d + 2);
-    const int z = pz - 1, y = py - 1, xx = px - 1;
-    float v = 0.f;
-    if ((unsigned)z < (unsigned)d && (unsigned)y < (unsigned)h && (unsigned)xx < (unsigned)w)
-        v = x[(((size_t)nb * d + z) * h + y) * w + xx];
-    xp[(((size_t)nb * (d + 2) + pz) * (h + 2) + py) * (w + 2) + px] = v;
+    const int nb = blockIdx.x / (d + 2), pz = blockIdx.x - nb * (d + 2);
+    const int z = pz - 1;
+    const int pw = w + 2, plane = (h + 2) * pw;
+    float* const dst = xp + (size_t)blockIdx.x * plane;
+    if ((unsigned)z >= (unsigned)d) {
+        for (int i = threadIdx.x; i < plane; i += blockDim.x) dst[i] = 0.f;
+        return;
+    }
+    const float* const src = x + ((size_t)nb * d + z) * h * w;
+    for (int i = threadIdx.x; i < plane; i += blockDim.x) {
+        const int py = i / pw, px = i - py * pw;
+        const int y = py - 1, xx = px - 1;
+        dst[i] = ((unsigned)y < (unsigned)h && (unsigned)xx < (unsigned)w) ? src[y * w + xx] : 0.f;
+    }
 }
 
 template <typename T, int MT>
@@ -656,8 +661,7 @@ int launch_conv_first(int dtype, const float* x, float* xpad, const float* w, co
     const size_t blocks = (nvox + 4 * MT * 32 - 1) / (4 * MT * 32);
     EXA_CHECK_ARG(nvox > 0 && nvox < 0x7fffffffULL && c0p % 32 == 0, "conv_first: bad size");
     EXA_CHECK_ARG((long long)n * (d + 2) <= 65535 && h + 2 <= 65535, "conv_first: grid too large");
-    const dim3 pgrid((wd + 2 + 127) / 128, h + 2, n * (d + 2));
-    pad_input_kernel<<<pgrid, 128, 0, stream>>>(x, xpad, d, h, wd);
+    pad_input_kernel<<<(unsigned)((long long)n * (d + 2)), 256, 0, stream>>>(x, xpad, d, h, wd);
     EXA_CHECK_HIP(hipGetLastError());
     dim3 grid((unsigned)blocks, c0p / 32);
     // the 16-bit kernel's waves walk the 32-voxel groups: 8 workgroups per CU are plenty

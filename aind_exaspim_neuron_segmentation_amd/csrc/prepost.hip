@@ -202,9 +202,9 @@ __device__ __forceinline__ bool covered(const int* s, const exaspim_window& w, c
            x < min(x0 + ox, g[2]);
 }
 
-// Grid: x = voxels of one trimmed output row, y = row, z = patch * trimmed depth.
+// Grid: x = blocks of voxels of one trimmed output plane, y = patch * trimmed depth.
 template <int C>
-__global__ __launch_bounds__(128) void stitch_kernel(const float* __restrict__ pred,
+__global__ __launch_bounds__(256) void stitch_kernel(const float* __restrict__ pred,
                                                      const int* __restrict__ starts, int n,
                                                      exaspim_window win,
                                                      float* __restrict__ accum,
@@ -213,9 +213,9 @@ __global__ __launch_bounds__(128) void stitch_kernel(const float* __restrict__ p
               ox = win.patch[2] - 2 * win.trim;
     const size_t pvox = (size_t)win.patch[0] * win.patch[1] * win.patch[2];
     const size_t avox = (size_t)blk.dims[0] * blk.dims[1] * blk.dims[2];
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    const int p = blockIdx.z / oz, z = blockIdx.z - p * oz;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // voxel inside the trimmed plane
+    const int y = i / ox, x = i - y * ox;
+    const int p = blockIdx.y / oz, z = blockIdx.y - p * oz;
     const int* sp = starts + 3 * p;
 
     // Patches of the batch whose trimmed box meets patch p's (one ballot per
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(128) void stitch_kernel(const float* __restrict__ p
         }
         __syncthreads();
     }
-    if (x >= ox) return;
+    if (y >= oy) return;
     const int gz = sp[0] + win.trim + z, gy = sp[1] + win.trim + y, gx = sp[2] + win.trim + x;
     if (gz >= blk.global[0] || gy >= blk.global[1] || gx >= blk.global[2]) return;
     const int lz = gz - blk.origin[0], ly = gy - blk.origin[1], lx = gx - blk.origin[2];
@@ -452,14 +452,14 @@ extern "C" int exaspim_stitch_accumulate(const float* pred_dev, const int32_t* s
     EXA_CHECK_ARG(n > 0 && channels >= 1 && channels <= 4, "stitch: n %d channels %d", n, channels);
     const int oz = win->patch[0] - 2 * win->trim, oy = win->patch[1] - 2 * win->trim,
               ox = win->patch[2] - 2 * win->trim;
-    EXA_CHECK_ARG((long long)n * oz <= 65535 && oy <= 65535, "stitch: grid too large");
-    const dim3 grid((ox + 127) / 128, oy, n * oz);
+    EXA_CHECK_ARG((long long)n * oz <= 65535 && (long long)oy * ox < 0x7fffffffLL, "stitch: grid too large");
+    const dim3 grid((unsigned)(((long long)oy * ox + 255) / 256), n * oz);
     hipStream_t s = (hipStream_t)stream;
     switch (channels) {
-        case 1: stitch_kernel<1><<<grid, 128, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
-        case 2: stitch_kernel<2><<<grid, 128, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
-        case 3: stitch_kernel<3><<<grid, 128, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
-        case 4: stitch_kernel<4><<<grid, 128, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
+        case 1: stitch_kernel<1><<<grid, 256, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
+        case 2: stitch_kernel<2><<<grid, 256, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
+        case 3: stitch_kernel<3><<<grid, 256, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
+        case 4: stitch_kernel<4><<<grid, 256, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
     }
     EXA_CHECK_HIP(hipGetLastError());
     return EXASPIM_OK;
