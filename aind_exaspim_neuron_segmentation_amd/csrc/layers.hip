@@ -510,12 +510,12 @@ __device__ __forceinline__ void lerp_coord(int o, int in, float scale, int& i0, 
     l1 = fminf(fmaxf(s - (float)i0, 0.f), 1.f);
 }
 
-// Grid: x = (volume, pair of output planes), y = blocks of 16-byte pieces of a plane. A
-// thread produces the same (y, x, group) piece of two consecutive output planes: their
+// Grid: x = (volume, pair of output planes), y = blocks of voxels of a plane. A thread
+// produces one voxel record (both 16-byte groups) of two consecutive output planes: their
 // z interpolation coordinates are scalar, they share the in-plane weights, and together
 // they touch three (at most four) source planes, each interpolated in-plane once --
 // torch's own nesting, d0 * (h0 * (w0 v000 + w1 v001) + h1 * (...)) + d1 * (...).
-// "row_magic" = floor(2^32 / row pieces) + 1 turns the row split into a multiply-high
+// "row_magic" = floor(2^32 / row voxels) + 1 turns the row split into a multiply-high
 // (exact for the plane sizes the launcher admits).
 template <typename T>
 __global__ __launch_bounds__(256) void upsample2_kernel(const uint4* __restrict__ src,
@@ -524,15 +524,15 @@ __global__ __launch_bounds__(256) void upsample2_kernel(const uint4* __restrict_
                                                         float sy, float sx, int margin) {
     // output voxels closer than "margin" to a face are not needed by the caller
     constexpr int cg = 2;  // 16-byte groups of a 32-byte record
-    constexpr int NF = T::kG / 2;
+    constexpr int NF = T::kG;   // float pairs of a record (two groups)
     typedef float f2 __attribute__((ext_vector_type(2)));
     const int od = d * 2, oh = h * 2, ow = w * 2;
-    const int nz = od - 2 * margin, ny = oh - 2 * margin, rowp = (ow - 2 * margin) * cg;
+    const int nz = od - 2 * margin, ny = oh - 2 * margin, rowv = ow - 2 * margin;
     const int nzp = (nz + 1) >> 1;
-    const unsigned i = blockIdx.y * blockDim.x + threadIdx.x;  // piece inside the needed plane
-    if (i >= (unsigned)(ny * rowp)) return;
-    const int yy = (int)__umulhi(i, row_magic), ix = (int)i - yy * rowp;
-    const int y = margin + yy, x = margin + (ix >> 1), g = ix & 1;
+    const unsigned i = blockIdx.y * blockDim.x + threadIdx.x;  // voxel inside the needed plane
+    if (i >= (unsigned)(ny * rowv)) return;
+    const int yy = (int)__umulhi(i, row_magic);
+    const int y = margin + yy, x = margin + ((int)i - yy * rowv);
     const int nb = blockIdx.x / nzp, za = margin + 2 * (blockIdx.x - nb * nzp);
     const bool has_b = za + 1 < od - margin;
     int a0, a1, b0, b1, y0, y1, x0, x1;
@@ -542,36 +542,43 @@ __global__ __launch_bounds__(256) void upsample2_kernel(const uint4* __restrict_
     lerp_coord(y, h, sy, y0, y1, ly);
     lerp_coord(x, w, sx, x0, x1, lx);
     const f2 wx0 = {1.f - lx, 1.f - lx}, wx1 = {lx, lx}, wy0 = {1.f - ly, 1.f - ly}, wy1 = {ly, ly};
-    const uint4* base = src + (size_t)nb * d * h * w * cg + g;
+    const uint4* base = src + (size_t)nb * d * h * w * cg;
     const int o00 = (y0 * w + x0) * cg, o01 = (y0 * w + x1) * cg, o10 = (y1 * w + x0) * cg,
               o11 = (y1 * w + x1) * cg;
 
-    // in-plane interpolation of source plane zp (wave-uniform)
+    // in-plane interpolation of source plane zp (wave-uniform), both groups of the record
     auto plane = [&](int zp, f2* p) {
         const uint4* pl = base + (size_t)zp * h * w * cg;
-        float v00[T::kG], v01[T::kG], v10[T::kG], v11[T::kG];
-        T::unpack(pl[o00], v00);
-        T::unpack(pl[o01], v01);
-        T::unpack(pl[o10], v10);
-        T::unpack(pl[o11], v11);
 #pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            const f2 r0 = __builtin_elementwise_fma(wx1, (f2){v01[2 * j], v01[2 * j + 1]},
-                                                    wx0 * (f2){v00[2 * j], v00[2 * j + 1]});
-            const f2 r1 = __builtin_elementwise_fma(wx1, (f2){v11[2 * j], v11[2 * j + 1]},
-                                                    wx0 * (f2){v10[2 * j], v10[2 * j + 1]});
-            p[j] = __builtin_elementwise_fma(wy1, r1, wy0 * r0);
+        for (int g = 0; g < cg; ++g) {
+            float v00[T::kG], v01[T::kG], v10[T::kG], v11[T::kG];
+            T::unpack(pl[o00 + g], v00);
+            T::unpack(pl[o01 + g], v01);
+            T::unpack(pl[o10 + g], v10);
+            T::unpack(pl[o11 + g], v11);
+#pragma unroll
+            for (int j = 0; j < T::kG / 2; ++j) {
+                const f2 r0 = __builtin_elementwise_fma(wx1, (f2){v01[2 * j], v01[2 * j + 1]},
+                                                        wx0 * (f2){v00[2 * j], v00[2 * j + 1]});
+                const f2 r1 = __builtin_elementwise_fma(wx1, (f2){v11[2 * j], v11[2 * j + 1]},
+                                                        wx0 * (f2){v10[2 * j], v10[2 * j + 1]});
+                p[g * (T::kG / 2) + j] = __builtin_elementwise_fma(wy1, r1, wy0 * r0);
+            }
         }
     };
     auto store = [&](int z, const f2* p0, const f2* p1, float l) {
         const f2 w0 = {1.f - l, 1.f - l}, w1 = {l, l};
-        float out[T::kG];
+        uint4* rec = dst + ((((size_t)nb * od + z) * oh + y) * ow + x) * cg;
 #pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            const f2 v = __builtin_elementwise_fma(w1, p1[j], w0 * p0[j]);
-            out[2 * j] = v.x; out[2 * j + 1] = v.y;
+        for (int g = 0; g < cg; ++g) {
+            float out[T::kG];
+#pragma unroll
+            for (int j = 0; j < T::kG / 2; ++j) {
+                const f2 v = __builtin_elementwise_fma(w1, p1[g * (T::kG / 2) + j], w0 * p0[g * (T::kG / 2) + j]);
+                out[2 * j] = v.x; out[2 * j + 1] = v.y;
+            }
+            rec[g] = T::pack(out);
         }
-        dst[((((size_t)nb * od + z) * oh + y) * ow + x) * cg + g] = T::pack(out);
     };
 
     f2 pa0[NF], pa1[NF];
@@ -720,10 +727,9 @@ int launch_maxpool2(int dtype, const void* src, void* dst, int n, int d, int h, 
 int launch_upsample2(int dtype, const void* src, void* dst, int n, int d, int h, int w,
                      int c, int margin, hipStream_t stream) {
     if (margin < 0 || margin >= d || margin >= h || margin >= w) margin = 0;
-    constexpr int cg = 2;                              // 16-byte groups of a 32-byte record
     const int nv = n * (c * dtype_size(dtype) / 32);   // chunk planes = independent volumes
-    const long long plane = (long long)(h * 2 - 2 * margin) * (w * 2 - 2 * margin) * cg;
-    const long long rowp = (long long)(w * 2 - 2 * margin) * cg;
+    const long long plane = (long long)(h * 2 - 2 * margin) * (w * 2 - 2 * margin);   // voxels
+    const long long rowp = (long long)(w * 2 - 2 * margin);
     const long long planes = (long long)nv * ((d * 2 - 2 * margin + 1) / 2);   // pairs of output planes
     EXA_CHECK_ARG(planes <= 0x7fffffffLL && (plane + 255) / 256 <= 65535 && plane * rowp < 0xffffffffLL,
                   "upsample: grid too large");
