@@ -115,6 +115,12 @@ struct ConvArgs {
     // pool_dst as (n, cout, d/2, h/2, w/2) in the same layout (z-column kernel only:
     // ask conv_can_fuse_pool first); saves re-reading the whole skip tensor.
     void* pool_dst = nullptr;
+    // Optional scratch for split-K (t14 kernel): launches with too few workgroups to fill
+    // the device cut the input-channel chunks into up to 4 ranges, every range writes its
+    // float32 partial sums here and a second kernel adds them in a fixed order.
+    float* partial = nullptr;
+    size_t partial_bytes = 0;
+    int ksplit = 1;      // set by the launcher
 #ifdef EXASPIM_TRACE
     // tools/conv_trace.hip only: 16 x 64-bit cycle stamps per wave (never in the library build)
     unsigned long long* trace = nullptr;

@@ -263,7 +263,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 b = *reinterpret_cast<const float4*>(a.bias + (ntile0 + nt) * 32 + 8 * q + 4 * half);
+            // (split-K ranges start from zero; the reduction adds the bias)
+            float4 b = *reinterpret_cast<const float4*>(a.bias + (ntile0 + nt) * 32 + 8 * q + 4 * half);
+            if (a.ksplit > 1) b = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 acc[mt][nt][4 * q + 0] = b.x; acc[mt][nt][4 * q + 1] = b.y;
@@ -271,7 +273,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
             }
         }
 
-    const int nchunks = (a.ca + a.cb) / KC;
+    // this workgroup's range of input-channel chunks (all of them unless split-K)
+    const int nchunks_all = (a.ca + a.cb) / KC;
+    const int cbeg = (int)blockIdx.z * nchunks_all / a.ksplit;
+    const int nchunks = ((int)blockIdx.z + 1) * nchunks_all / a.ksplit;
     uint4 stg[NITEMS];
 
     auto stage_load = [&](int c) {
@@ -304,13 +309,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
                                   (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
 #endif
     EXA_TRACE(0);
-    stage_load(0);
+    stage_load(cbeg);
     EXA_TRACE(1);
     stage_store();
     __syncthreads();
     EXA_TRACE(2);
 
-    for (int c = 0; c < nchunks; ++c) {
+    for (int c = cbeg; c < nchunks; ++c) {
         const uint4* wp = static_cast<const uint4*>(a.weights) +
                           ((size_t)c * 27 * ntiles + ntile0) * 64 + lane;
         uint4 wring[PD + 1][NT];
@@ -346,14 +351,37 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
             // this fence hipcc hoists and sinks them across taps and the loop runs ~20 % slower
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (c < 4) EXA_TRACE(3 + 3 * c);
+        if (c - cbeg < 4) EXA_TRACE(3 + 3 * (c - cbeg));
         __syncthreads();  // every wave is done reading this chunk's image
-        if (c < 4) EXA_TRACE(4 + 3 * c);
+        if (c - cbeg < 4) EXA_TRACE(4 + 3 * (c - cbeg));
         if (more) {
             stage_store();
             __syncthreads();
-            if (c < 3) EXA_TRACE(5 + 3 * c);
+            if (c - cbeg < 3) EXA_TRACE(5 + 3 * (c - cbeg));
         }
+    }
+
+    if (a.ksplit > 1) {
+        // ---- split-K: float32 partial sums, [range][patch][voxel][cout] ------------------
+        float* const part = a.partial + ((size_t)blockIdx.z * a.n + nb) * patch_vox * a.cout;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = (wm * MT + mt) * 32 + r;
+            const int z = m / (TY * TX), y = (m / TX) % TY, x = m % TX;
+            const int gz = z0 + z, gy = y0 + y, gx = x0 + x;
+            if (m < TILE_VOX && gz < a.d && gy < a.h && gx < a.w) {
+                float* rec = part + (((size_t)gz * a.h + gy) * a.w + gx) * a.cout;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4*>(rec + (ntile0 + nt) * 32 + 8 * q + 4 * half) =
+                            make_float4(acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2],
+                                        acc[mt][nt][4 * q + 3]);
+            }
+        }
+        EXA_TRACE(14);
+        return;
     }
 
     // ---- epilogue: bias + LeakyReLU, transposed through LDS ------------------
@@ -873,6 +901,33 @@ static int launch_zpipe(const ConvArgs& a, hipStream_t stream) {
     return EXASPIM_OK;
 }
 
+// Split-K reduction: adds the float32 partial sums of the chunk ranges in range order, then
+// bias, LeakyReLU and the conversion, and writes four channels of one voxel in the blocked
+// layout. One thread per (voxel, 4 channels).
+template <typename Tag>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial,
+                                                            const float* __restrict__ bias,
+                                                            void* __restrict__ dst, size_t nvox_all,
+                                                            size_t patch_vox, int cout, int ksplit,
+                                                            float slope) {
+    constexpr int ES = 16 / Tag::kG;
+    constexpr int KC = 2 * Tag::kG;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int quads = cout >> 2;
+    if (i >= nvox_all * quads) return;
+    const size_t v = i / quads;
+    const int c = (int)(i - v * quads) * 4;
+    float4 s = *reinterpret_cast<const float4*>(bias + c);
+    for (int k = 0; k < ksplit; ++k) {
+        const float4 p = *reinterpret_cast<const float4*>(partial + ((size_t)k * nvox_all + v) * cout + c);
+        s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    }
+    const size_t nb = v / patch_vox, vox = v - nb * patch_vox;
+    char* out = static_cast<char*>(dst) + (((size_t)nb * (cout / KC) + c / KC) * patch_vox + vox) * 32 +
+                (c % KC) * ES;
+    store4<Tag>(out, 0, leaky(s.x, slope), leaky(s.y, slope), leaky(s.z, slope), leaky(s.w, slope));
+}
+
 // ---- host side: pick a tile configuration per layer -----------------------
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -889,10 +944,30 @@ static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
         set_error("conv: grid of %lld blocks out of range", blocks);
         return EXASPIM_E_INVALID;
     }
-    dim3 grid((unsigned)blocks, a.cout / NWG);
+    // Split-K when the launch cannot give every CU two workgroups: up to 4 ranges of chunks
+    // (one at least per range), if the scratch holds the partial sums.
+    ConvArgs b = a;
+    b.ksplit = 1;
+    const long long wgs = blocks * (a.cout / NWG);
+    const int nchunks = (a.ca + a.cb) / (2 * Tag::kG);
+    const size_t nvox_all = (size_t)a.n * a.d * a.h * a.w;
+    if (a.partial && !a.head_out && !a.pool_dst && wgs * 2 <= resident_workgroups(2)) {
+        int ks = (int)(resident_workgroups(2) / wgs);
+        if (ks > 4) ks = 4;
+        if (ks > nchunks) ks = nchunks;
+        while (ks > 1 && (size_t)ks * nvox_all * a.cout * sizeof(float) > a.partial_bytes) --ks;
+        b.ksplit = ks;
+    }
+    dim3 grid((unsigned)blocks, a.cout / NWG, b.ksplit);
     conv3x3x3_t14<Tag, TZ, TY, TX, WAVES_M, WAVES_N, MT, NT, MINW, PD>
-        <<<grid, WAVES_M * WAVES_N * 64, 0, stream>>>(a, tz, ty, tx);
+        <<<grid, WAVES_M * WAVES_N * 64, 0, stream>>>(b, tz, ty, tx);
     EXA_CHECK_HIP(hipGetLastError());
+    if (b.ksplit > 1) {
+        const size_t items = nvox_all * (a.cout / 4);
+        splitk_reduce_kernel<Tag><<<(unsigned)((items + 255) / 256), 256, 0, stream>>>(
+            a.partial, a.bias, a.dst, nvox_all, (size_t)a.d * a.h * a.w, a.cout, b.ksplit, a.slope);
+        EXA_CHECK_HIP(hipGetLastError());
+    }
     return EXASPIM_OK;
 }
 

@@ -106,6 +106,9 @@ static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, in
         const ConvLayer& L = p.conv[idx];
         ConvArgs a;
         // inc.3 can write its own 2x2x2 max-pool (the input of down1) next to its output
+        // split-K scratch: the zero-bordered input copy is dead once inc.0 has run
+        a.partial = reinterpret_cast<float*>(base + ws.xpad);
+        a.partial_bytes = ws.bytes - ws.xpad;
         if (idx == 0 && fuse_pool) a.pool_dst = A(1);
         if (trimmed && idx == kNumMfmaConvs - 1) a.margin = trim;
         if (trimmed && idx == kNumMfmaConvs - 2) a.margin = trim - 1;
