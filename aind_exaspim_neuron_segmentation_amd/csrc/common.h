@@ -119,7 +119,7 @@ struct ConvArgs {
     // the device cut the input-channel chunks into up to 4 ranges, every range writes its
     // float32 partial sums here and a second kernel adds them in a fixed order.
     float* partial = nullptr;
-    size_t partial_bytes = 0;
+    size_t partial_patch_bytes = 0;   // scratch bytes per patch of the batch
     int ksplit = 1;      // set by the launcher
 #ifdef EXASPIM_TRACE
     // tools/conv_trace.hip only: 16 x 64-bit cycle stamps per wave (never in the library build)

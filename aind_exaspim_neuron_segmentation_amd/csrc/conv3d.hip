@@ -148,6 +148,12 @@ __device__ __forceinline__ void store4<BF16Tag>(void* dst, size_t off, float a, 
 template <>
 __device__ __forceinline__ void store4<F16Tag>(void* dst, size_t off, float a, float b, float c, float d) {
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    // saturate to the largest finite half: an activation beyond +-65504 is stored as
+    // +-65504 instead of +-inf (one v_med3_f32 per value, epilogue only)
+    a = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);
+    b = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
+    c = __builtin_amdgcn_fmed3f(c, -65504.f, 65504.f);
+    d = __builtin_amdgcn_fmed3f(d, -65504.f, 65504.f);
     f16x4 v = {(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d};
     *reinterpret_cast<f16x4*>(static_cast<_Float16*>(dst) + off) = v;
 }
@@ -944,18 +950,24 @@ static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
         set_error("conv: grid of %lld blocks out of range", blocks);
         return EXASPIM_E_INVALID;
     }
-    // Split-K when the launch cannot give every CU two workgroups: up to 4 ranges of chunks
-    // (one at least per range), if the scratch holds the partial sums.
+    // Split-K when a launch of a nominal batch (16 patches) cannot give every CU two
+    // workgroups: up to 4 ranges of chunks (one at least per range), if the scratch holds
+    // the partial sums. The split changes the order in which a voxel's products are
+    // summed, so it is a function of the layer and the patch size only, never of the batch
+    // size: a patch gets the same bits whichever batch it travels in (predict_streaming
+    // relies on that; short batches merely fill the device less well).
     ConvArgs b = a;
     b.ksplit = 1;
-    const long long wgs = blocks * (a.cout / NWG);
+    constexpr int kNominalBatch = 16;
+    const long long wgs = (long long)tz * ty * tx * kNominalBatch * (a.cout / NWG);
     const int nchunks = (a.ca + a.cb) / (2 * Tag::kG);
-    const size_t nvox_all = (size_t)a.n * a.d * a.h * a.w;
+    const size_t patch_vox_all = (size_t)a.d * a.h * a.w;
+    const size_t nvox_all = (size_t)a.n * patch_vox_all;
     if (a.partial && !a.head_out && !a.pool_dst && wgs * 2 <= resident_workgroups(2)) {
         int ks = (int)(resident_workgroups(2) / wgs);
         if (ks > 4) ks = 4;
         if (ks > nchunks) ks = nchunks;
-        while (ks > 1 && (size_t)ks * nvox_all * a.cout * sizeof(float) > a.partial_bytes) --ks;
+        while (ks > 1 && (size_t)ks * patch_vox_all * a.cout * sizeof(float) > a.partial_patch_bytes) --ks;
         b.ksplit = ks;
     }
     dim3 grid((unsigned)blocks, a.cout / NWG, b.ksplit);

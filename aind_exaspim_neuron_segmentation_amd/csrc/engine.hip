@@ -27,7 +27,7 @@ struct Workspace {
 // (exaspim_unet_timing_*): a ring of event pairs around the MFMA convolutions
 // selected by a layer mask.
 struct LayerTimer {
-    static constexpr int kRing = 4096;
+    static constexpr int kRing = 16384;
     uint32_t mask = 0;
     int next = 0, used = 0;
     hipEvent_t start[kRing], stop[kRing];
@@ -108,7 +108,7 @@ static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, in
         // inc.3 can write its own 2x2x2 max-pool (the input of down1) next to its output
         // split-K scratch: the zero-bordered input copy is dead once inc.0 has run
         a.partial = reinterpret_cast<float*>(base + ws.xpad);
-        a.partial_bytes = ws.bytes - ws.xpad;
+        a.partial_patch_bytes = (size_t)(d + 2) * (h + 2) * (w + 2) * sizeof(float);
         if (idx == 0 && fuse_pool) a.pool_dst = A(1);
         if (trimmed && idx == kNumMfmaConvs - 1) a.margin = trim;
         if (trimmed && idx == kNumMfmaConvs - 2) a.margin = trim - 1;

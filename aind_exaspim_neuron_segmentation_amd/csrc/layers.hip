@@ -62,7 +62,9 @@ struct F16T {
         unsigned w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const _Float16 lo = (_Float16)f[2 * i], hi = (_Float16)f[2 * i + 1];
+            // saturating conversion (largest finite half instead of +-inf)
+            const _Float16 lo = (_Float16)__builtin_amdgcn_fmed3f(f[2 * i], -65504.f, 65504.f);
+            const _Float16 hi = (_Float16)__builtin_amdgcn_fmed3f(f[2 * i + 1], -65504.f, 65504.f);
             w[i] = (unsigned)__builtin_bit_cast(unsigned short, lo) |
                    ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
         }

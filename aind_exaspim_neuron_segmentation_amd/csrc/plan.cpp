@@ -150,6 +150,9 @@ static inline uint16_t f32_to_bf16_rne(float f) {
 }
 
 static inline uint16_t f32_to_f16_rne(float f) {
+    // saturating, like the kernels' stores: a folded weight beyond +-65504 stays finite
+    if (f > 65504.f) f = 65504.f;
+    if (f < -65504.f) f = -65504.f;
     _Float16 h = (_Float16)f;
     uint16_t u;
     std::memcpy(&u, &h, 2);

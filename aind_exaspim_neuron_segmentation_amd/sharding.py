@@ -92,6 +92,19 @@ class Shard:
                     f"axis {axis}: {len(axis_starts[axis])} patch starts cannot be split {parts} ways"
                 )
             self.ranges.append(_split(len(axis_starts[axis]), parts, idx))
+            # exchange_output_bands hands the overlap band one rank forward along an
+            # axis and no further: the band must fit into the owned extent of every
+            # rank that receives one and passes its own on (the interior ranks)
+            band = p[axis] - 2 * trim - (p[axis] - ov[axis])
+            for j in range(1, parts - 1):
+                lo_j, hi_j = _split(len(axis_starts[axis]), parts, j)
+                extent = (hi_j - lo_j) * (p[axis] - ov[axis])
+                if band > extent:
+                    raise ValueError(
+                        f"axis {axis}: the {band}-voxel overlap band does not fit into the "
+                        f"{extent}-voxel region of rank {j} of {parts}; use fewer ranks along "
+                        "this axis or a larger stride"
+                    )
         mine = [axis_starts[a][lo:hi] for a, (lo, hi) in enumerate(self.ranges)]
         self.starts = [(z, y, x) for z in mine[0] for y in mine[1] for x in mine[2]]
 
@@ -293,7 +306,7 @@ def exchange_input_halo(core, shard, group):
 
 def predict_shard(volume, model, plan, shard, n_channels=3, batch_size=16,
                   brightness_clip=1000, normalization_percentiles=(1, 99.9), group=None,
-                  n_streams=1):
+                  n_streams=1, timings=None):
     """
     Runs one rank's share of predict() on its device: global percentiles
     (histogram all-reduce), the rank's patches, the band exchange and the final
@@ -312,7 +325,13 @@ def predict_shard(volume, model, plan, shard, n_channels=3, batch_size=16,
         This rank's shard.
     group : ProcessGroup, optional
         Process group (None = single process).
+    timings : dict, optional
+        If given, timings["seconds"] is increased by the wall time this rank
+        spends in the two exchange steps (histogram all-reduce, output bands),
+        measured between device synchronisations.
     """
+    import time
+
     from aind_exaspim_neuron_segmentation_amd import inference
 
     device = volume.tensor.device
@@ -330,7 +349,13 @@ def predict_shard(volume, model, plan, shard, n_channels=3, batch_size=16,
         )
 
         def reduce_fn(hist):
+            if timings is not None:
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
             all_reduce_sum(hist, group)
+            if timings is not None:
+                torch.cuda.synchronize(device)
+                timings["seconds"] = timings.get("seconds", 0.0) + time.perf_counter() - t0
 
         mn, mx = inference.volume_percentiles(core, brightness_clip, normalization_percentiles,
                                               reduce_fn=reduce_fn)
@@ -343,7 +368,13 @@ def predict_shard(volume, model, plan, shard, n_channels=3, batch_size=16,
         starts=shard.starts, accum_block=accum_block, n_streams=n_streams,
     )
     if multi:
+        if timings is not None:
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
         exchange_output_bands(accum, shard, group)
+        if timings is not None:
+            torch.cuda.synchronize(device)
+            timings["seconds"] = timings.get("seconds", 0.0) + time.perf_counter() - t0
     inference.stitch_finalize(accum, plan, accum_block)
     return accum
 

@@ -1,44 +1,54 @@
 """
 Benchmark of the hot path: affinity voxels/sec of the sliding-window 3D-UNet
-prediction over a synthetic volume resident in HBM.
+prediction over a synthetic volume.
 
   python bench.py --gpus N --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
-         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+With N > 1 and no WORLD_SIZE in the environment this process only LAUNCHES: it
+starts N fresh child processes of this script (one rank per GPU, RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set) before it
+touches the GPU in any way, waits for them and exits non-zero if one fails.
+Under `python -m torch.distributed.run ... bench.py --gpus N` the ranks exist
+already and each process is one of them.
 
 A "step" is one full pass of predict()'s device pipeline over the volume:
 histogram -> percentiles -> for every batch of patches (gather+normalise ->
-U-Net -> sigmoid -> trimmed overlap-add) -> divide by coverage. Input (uint16)
-and output (float32 x3) stay in HBM; no host copies inside the timed region
-(the PCIe-inclusive rate is reported separately in DESIGN.md).
+U-Net -> sigmoid -> trimmed overlap-add) -> divide by coverage. `value` keeps
+input (uint16) and output (float32 x3) in HBM; the host-array-to-host-array
+rate of the same call (upload, slab-wise download overlapped with compute) is
+reported next to it as `host_to_host` at N = 1.
 
-Workload at N = 1: BASELINE.json configs[2] -- 1024^3 volume, 96^3 patches,
-overlap 32, trim 8, batch 16, bf16 activations / fp32 accumulation. At N > 1
-the volume grows with N (weak scaling, 1024^3 per GPU): the global patch grid
-is partitioned by sub-volume over a (z, y) rank grid and only the 16-voxel
-output overlap bands travel between neighbours (RCCL send/recv over xGMI).
+Workloads (BASELINE.json configs, --size scales the 1024 edge):
+  N = 1  1024 x 1024 x 1024              configs[2], batch 16, 16-bit storage / fp32 accumulate
+  N = 2  2048 x 1024 x 1024, grid 2 x 1  configs[3]
+  N = 4  2048 x 2048 x 1024, grid 2 x 2
+  N = 8  4096 x 2048 x 2048, grid 4 x 2  configs[4]
+The global patch grid is partitioned by sub-volume over a (z, y) rank grid and
+only the 16-voxel output overlap bands travel between neighbours (RCCL
+send/recv over xGMI), plus a 512 KiB histogram all-reduce.
+
+16-bit mode: the default --dtype is fp16 (IEEE half storage of activations and
+weights, saturating stores, fp32 accumulation on v_mfma_f32_32x32x16_f16): it
+meets north_star's 1e-3 against the reference (measured 2.7e-4 max, `parity`
+block); bf16 storage runs at the same speed but sits at 2.3e-3 .. 2.9e-3.
 
 Rank 0 prints ONE JSON line with the contract fields plus "roofline" (dominant
-kernel, HIP-event timed on the launch stream) and "cpu_baseline" (the CPU
-oracle timed on this host's cores on a bounded sample).
+kernel, HIP-event timed on the launch stream), "parity" (this dtype against the
+reference's own 160^3 output, tests/golden/g6), "host_to_host" and
+"cpu_baseline" (the CPU oracle timed on this host's cores on a bounded sample).
 """
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-
-from aind_exaspim_neuron_segmentation_amd import _native, inference, sharding  # noqa: E402
-from aind_exaspim_neuron_segmentation_amd.machine_learning.unet3d import UNet3D  # noqa: E402
-from aind_exaspim_neuron_segmentation_amd.utils import synthetic  # noqa: E402
 
 FLOP_PER_PATCH_96 = 370_145_230_848  # 2 x MAC over the 19 convs
 PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense MFMA, MI355X_MICROARCH.md
@@ -47,6 +57,10 @@ PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense MFMA, MI3
 # (bit in the timing mask, Cin, Cout, edge)
 DOMINANT_CONVS = [(14, 64, 32, 48), (15, 64, 32, 96)]  # up3.3, up4.0
 TRIM = 8  # predict()'s default (inference.py:38)
+TIMER_RING = 16384  # launches the engine's event ring holds (csrc/engine.hip)
+# (z, y, x) extents in units of --size per world size: BASELINE.json configs[2], [3], -, [4]
+GLOBAL_SHAPES = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (4, 2, 2)}
+CONFIG_NAMES = {1: "configs[2]", 2: "configs[3]", 8: "configs[4]"}
 
 
 def parse_args():
@@ -54,10 +68,12 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=2)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
-    p.add_argument("--size", type=int, default=1024, help="volume edge per GPU")
+    p.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32"])
+    p.add_argument("--size", type=int, default=1024, help="edge of the per-GPU cube (1024 = BASELINE)")
     p.add_argument("--batch", type=int, default=16)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-host-to-host", action="store_true")
+    p.add_argument("--no-parity", action="store_true")
     p.add_argument("--streams", type=int, default=1,
                    help="batches in flight on separate HIP streams (default 1: kernels never share "
                         "the device, so the per-kernel roofline timing means what it says)")
@@ -65,8 +81,28 @@ def parse_args():
     return p.parse_args()
 
 
+def launch_ranks(args):
+    """Parent of an N-rank run: spawns the ranks and never initialises the GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [p.wait() for p in procs]
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        raise SystemExit(f"bench.py: ranks failed (rank, exit code): {bad}")
+
+
 def cpu_baseline(sample_edge, full_edge):
     """Times the CPU oracle (torch CPU fp32, all host cores) on a bounded sample."""
+    import numpy as np
+    import torch
+
+    from aind_exaspim_neuron_segmentation_amd.utils import synthetic
     from oracle import reference_path as oracle
 
     sd = synthetic.synth_state_dict(3, 1, seed=1)
@@ -94,13 +130,86 @@ def cpu_baseline(sample_edge, full_edge):
     }
 
 
+def parity_block(model, dtype):
+    """The benchmarked model (same weights, same compute dtype) on the reference's
+    default-config 160^3 case against the reference's own output (golden g6)."""
+    import numpy as np
+
+    from aind_exaspim_neuron_segmentation_amd import inference
+    from aind_exaspim_neuron_segmentation_amd.utils import synthetic
+
+    path = os.path.join(ROOT, "tests", "golden", "g6_default_160.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path, allow_pickle=False)
+    vol = synthetic.synth_volume((160, 160, 160), seed=0)
+    got = inference.predict(vol, model, batch_size=8, verbose=False)
+    err = np.abs(got[:, ::5, ::5, ::5] - g["pred_sub"])
+    return {
+        "against": "reference predict() on 160^3, defaults (tests/golden/g6_default_160.npz)",
+        "dtype": dtype,
+        "max": float(err.max()),
+        "mean": float(err.mean()),
+        "p99_9": float(np.quantile(err, 0.999)),
+        "tolerance": 1e-3,
+        "weights": "seeded random (no checkpoint ships with the reference)",
+    }
+
+
+def host_to_host(model, args, edge):
+    """predict() from a host numpy array to a host numpy array on the N = 1 workload."""
+    import numpy as np
+    import torch
+
+    from aind_exaspim_neuron_segmentation_amd import _native, inference
+
+    dev = next(model.parameters()).device
+    vol_t = torch.empty((edge,) * 3, dtype=torch.int16, device=dev)
+    blk = _native.Block.make((edge,) * 3, (0, 0, 0), (edge,) * 3)
+    _native.check(_native.lib().exaspim_synth_volume_u16(vol_t.data_ptr(), blk, 0, None), "synth")
+    vol = vol_t.cpu().numpy().view(np.uint16)
+    del vol_t
+    times = []
+    for _ in range(2):          # the first call also page-locks the staging buffers
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = inference.predict(vol, model, batch_size=args.batch, verbose=False, n_streams=args.streams)
+        times.append(time.perf_counter() - t0)
+    dt = times[-1]
+    return {
+        "value": float(edge) ** 3 / dt,
+        "unit": "voxels/s",
+        "ms_per_step": dt * 1e3,
+        "first_call_ms": times[0] * 1e3,
+        "what": "inference.predict(numpy uint16 -> numpy float32 (3, D, H, W)): chunked upload + "
+                "histogram, finished 64-plane slabs downloaded to pinned memory on a copy stream and "
+                "moved into the pageable result by 4 host threads while later layers compute",
+        "output_checksum": float(out[:, ::7, ::7, ::7].sum(dtype=np.float64)),
+    }
+
+
 def main():
     args = parse_args()
+    if args.gpus not in GLOBAL_SHAPES:
+        raise SystemExit(f"--gpus {args.gpus}: supported world sizes are {sorted(GLOBAL_SHAPES)}")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)      # no torch.cuda call has happened in this process
+        return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import ctypes
+
+    import numpy as np
+    import torch
+
+    from aind_exaspim_neuron_segmentation_amd import _native, inference, sharding
+    from aind_exaspim_neuron_segmentation_amd.machine_learning.unet3d import UNet3D
+    from aind_exaspim_neuron_segmentation_amd.utils import synthetic
+
     # one rank per GPU; EXASPIM_DIST_BACKEND=gloo lets several ranks rehearse the
     # sharded path on a single GPU (device index wraps, transfers staged via host)
     backend = os.environ.get("EXASPIM_DIST_BACKEND", "nccl")
@@ -122,10 +231,10 @@ def main():
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     model.to(device).eval()
 
-    # synthetic global volume, weak scaling over a (z, y) rank grid
+    # synthetic global volume over a (z, y) rank grid
     grid = sharding.rank_grid(world)
-    gshape = (args.size * grid[0], args.size * grid[1], args.size)
-    plan = inference.SlidingWindow(gshape, (96, 96, 96), (32, 32, 32), 8)
+    gshape = tuple(args.size * m for m in GLOBAL_SHAPES[world])
+    plan = inference.SlidingWindow(gshape, (96, 96, 96), (32, 32, 32), TRIM)
     shard = sharding.Shard(plan, grid, rank)
     vol_t = torch.empty(shard.input_dims, dtype=torch.int16, device=device)
     blk = _native.Block.make(shard.input_dims, shard.input_origin, gshape)
@@ -134,12 +243,13 @@ def main():
     )
     volume = inference.DeviceVolume(vol_t, np.uint16, shard.input_origin, gshape)
     torch.cuda.synchronize()
+    exchange = {"seconds": 0.0}
 
     def step():
         return sharding.predict_shard(
             volume, model, plan, shard, n_channels=3, batch_size=args.batch,
             brightness_clip=1000, normalization_percentiles=(1, 99.9), group=group,
-            n_streams=args.streams,
+            n_streams=args.streams, timings=exchange,
         )
 
     def barrier():
@@ -159,26 +269,28 @@ def main():
     for bit, _, _, _ in DOMINANT_CONVS:
         mask |= 1 << bit
     barrier()
+    exchange["seconds"] = 0.0
     _native.check(lib.exaspim_unet_timing_begin(model._engine, mask), "timing_begin")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    import ctypes
 
     ms = (ctypes.c_double * 17)()
     cnt = (ctypes.c_int32 * 17)()
     _native.check(lib.exaspim_unet_timing_read(model._engine, ctypes.byref(ms), ctypes.byref(cnt)),
                   "timing_read")
     checksum = float(out.sum().item())
+    del out
+    exchange_ms = exchange["seconds"] / max(args.steps, 1) * 1e3
     if group is not None:
         import torch.distributed as dist
 
-        t = torch.tensor([elapsed], dtype=torch.float64,
+        t = torch.tensor([elapsed, exchange_ms], dtype=torch.float64,
                          device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, exchange_ms = float(t[0].item()), float(t[1].item())
 
     if rank == 0:
         total_vox = float(gshape[0]) * gshape[1] * gshape[2]
@@ -200,20 +312,29 @@ def main():
         flops *= patches_per_step / float(full_batches * args.batch)
         achieved = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.dtype]
+        launches_per_step = len(DOMINANT_CONVS) * full_batches
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC
         # passes (FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md says;
         # profiles/summarize.py); null when no pass exists for this dtype.
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", f"r01_pmc_hbm_{args.dtype}.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                kernels = json.load(f).get("kernels", {})
-            tag = {"bf16": "BF16Tag", "fp16": "F16Tag", "fp32": "F32Tag"}[args.dtype]
-            entry = kernels.get(f"conv3x3x3_zpipe<{tag}, 6, 8, 16, 2, 4, 0, false>")
-            if entry:
-                traffic = entry["hbm_bytes_per_launch"]
+        for rnd in ("r02", "r01"):
+            tpath = os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm_{args.dtype}.json")
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    kernels = json.load(f).get("kernels", {})
+                tag = {"bf16": "BF16Tag", "fp16": "F16Tag", "fp32": "F32Tag"}[args.dtype]
+                entry = kernels.get(f"conv3x3x3_zpipe<{tag}, 6, 8, 16, 2, 4, 0, false>")
+                if entry:
+                    traffic = entry["hbm_bytes_per_launch"]
+                    break
+        # FLOPs of the work actually launched: the trimmed forward skips the margin of
+        # up4.0 (82^3 of 96^3) and up4.3 (80^3 of 96^3)
+        skipped = 2.0 * 27 * (64 * 32 * (96 ** 3 - 82 ** 3) + 32 * 32 * (96 ** 3 - 80 ** 3))
+        storage = {"fp16": "fp16 (IEEE half) storage", "bf16": "bf16 storage", "fp32": "fp32"}[args.dtype]
+        name = CONFIG_NAMES.get(world)
+        shape_txt = "x".join(str(v) for v in gshape)
         result = {
-            "metric": "affinity voxels/sec on 96^3 patches over a 1024^3 volume",
+            "metric": f"affinity voxels/sec on 96^3 patches over a {shape_txt} volume, {world} MI355X",
             "value": value,
             "unit": "voxels/s",
             "n_gpus": world,
@@ -226,14 +347,19 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": f"{gshape[0]}x{gshape[1]}x{gshape[2]} uint16 volume, 96^3 patches, "
-                            f"overlap 32, trim 8, batch {args.batch}, "
-                            f"{args.dtype} activations / fp32 accumulate (BASELINE.json configs[2] per GPU)",
+                "workload": f"{shape_txt} uint16 volume, 96^3 patches, overlap 32, trim 8, "
+                            f"batch {args.batch}, {storage} of activations and weights / fp32 accumulate"
+                            + (f" (BASELINE.json {name}" + (f", edge scaled to {args.size}" if args.size != 1024 else "") + ")"
+                               if name else " (between BASELINE.json configs[3] and configs[4])"),
                 "patches_per_step": patches_per_step * world,
                 "rank_grid_zy": list(grid),
-                "sharding": "global patch grid partitioned by sub-volume; 16-voxel output bands "
-                            "exchanged between neighbours" if world > 1 else "single device",
-                "tflops_end_to_end": value * FLOP_PER_PATCH_96 / 64 ** 3 / 1e12,
+                "sharding": ("global patch grid partitioned by sub-volume; per step a 512 KiB histogram "
+                             "all-reduce and the 16-voxel output bands to the +z / +y neighbours; every "
+                             "rank's input block (sub-volume + 32-voxel halo) is synthesised in place, "
+                             "so exchange_input_halo is not in the timed path") if world > 1 else "single device",
+                "exchange_ms": exchange_ms,
+                "reference_equivalent_tflops": value * FLOP_PER_PATCH_96 / 64 ** 3 / 1e12,
+                "launched_tflops": value * (FLOP_PER_PATCH_96 - skipped) / 64 ** 3 / 1e12,
                 "output_checksum": checksum,
                 "streams": args.streams,
             },
@@ -246,13 +372,22 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / peak,
                 "avg_launch_ms": k_ms / launches if launches else None,
-                "launches": launches,
+                "timed_launches": launches,
+                "steps_covered": launches / float(launches_per_step) if launches_per_step else None,
+                "timer_ring": TIMER_RING,
                 "traffic": traffic,
             },
         }
-        if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.size)
-        print(json.dumps(result))
+        if world == 1:
+            if not args.no_parity:
+                result["parity"] = parity_block(model, args.dtype)
+            if not args.no_host_to_host:
+                del volume, vol_t
+                torch.cuda.empty_cache()
+                result["host_to_host"] = host_to_host(model, args, args.size)
+            if not args.no_cpu_baseline:
+                result["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.size)
+        print(json.dumps(result), flush=True)
     if group is not None:
         import torch.distributed as dist
 

@@ -5,8 +5,12 @@ golden vectors produced by the reference itself.
 
 Tolerances: integer / index / byte work (percentiles, gather, stitch) is
 bit-exact; the fp32 network path is held to 1e-4 abs on logits and 1e-5 abs on
-probabilities (north_star allows 1e-3); bf16 / fp16 paths are reported and
-held to the tolerance written next to each assertion.
+probabilities (north_star allows 1e-3); the 16-bit mode that bench.py runs
+(fp16 storage, fp32 accumulate) is held to north_star's 1e-3 on the maximum;
+bf16 storage (8 significant bits) is held to 4e-3 (measured 2.3e-3 .. 2.9e-3)
+and is not the benchmarked mode. All weights are seeded random weights (no
+checkpoint ships with the reference): 16-bit parity on trained weights is
+unpinned.
 """
 
 import numpy as np
@@ -75,16 +79,17 @@ def test_unet_single_96_patch_vs_reference_golden(dev, oracle, golden):
     assert np.abs(sig - g["sigmoid_sub"]).max() < 1e-5
 
 
-@pytest.mark.parametrize("cdt,tol", [("bf16", 2e-2), ("fp16", 2e-3)])
+@pytest.mark.parametrize("cdt,tol", [("bf16", 4e-3), ("fp16", 1e-3)])
 def test_unet_16bit_paths_vs_oracle(dev, oracle, cdt, tol):
     # 16-bit storage of activations/weights, fp32 accumulate: tolerance on the
-    # probabilities, stated per dtype (bf16 has 8 significant bits).
+    # probabilities (max abs): fp16 = north_star's 1e-3; bf16 has 8 significant bits.
     model, sd = make_model(dev, compute_dtype=cdt)
     x = normalized_input(oracle, (32, 32, 32), seed=41, n=2)
     want = torch.sigmoid(oracle.unet_forward(x, oracle.OracleModel(sd).sd)).numpy()
     got = model.run(x.to(dev), apply_sigmoid=True).cpu().numpy()
     err = np.abs(got - want)
-    print(f"{cdt} probabilities: max {err.max():.3e} mean {err.mean():.3e}")
+    print(f"{cdt} probabilities: max {err.max():.3e} mean {err.mean():.3e} "
+          f"p99.9 {np.quantile(err, 0.999):.3e}")
     assert err.max() < tol
 
 
@@ -110,14 +115,15 @@ def test_conv_transpose_variant_vs_reference_golden_and_oracle(dev, oracle, gold
     assert e_pred < 1e-5
 
 
-@pytest.mark.parametrize("cdt,tol", [("bf16", 2e-2), ("fp16", 2e-3)])
+@pytest.mark.parametrize("cdt,tol", [("bf16", 4e-3), ("fp16", 1e-3)])
 def test_conv_transpose_variant_16bit(dev, oracle, cdt, tol):
     model, sd = make_model(dev, seed=8, compute_dtype=cdt, trilinear=False)
     x = normalized_input(oracle, (32, 32, 32), seed=62, n=3)
     want = torch.sigmoid(oracle.unet_forward(x, oracle.OracleModel(sd).sd)).numpy()
     got = model.run(x.to(dev), apply_sigmoid=True).cpu().numpy()
     err = np.abs(got - want)
-    print(f"convT {cdt} probabilities: max {err.max():.3e} mean {err.mean():.3e}")
+    print(f"convT {cdt} probabilities: max {err.max():.3e} mean {err.mean():.3e} "
+          f"p99.9 {np.quantile(err, 0.999):.3e}")
     assert err.max() < tol
 
 
@@ -505,11 +511,11 @@ def test_half_width_model_channel_padding(dev, oracle):
     assert np.abs(got - want).max() < 1e-4
 
 
-@pytest.mark.parametrize("cdt,tol", [("fp16", 1e-3), ("bf16", 1e-2)])
+@pytest.mark.parametrize("cdt,tol", [("fp16", 1e-3), ("bf16", 4e-3)])
 def test_predict_16bit_default_config_vs_reference_golden(dev, golden, cdt, tol):
     """Reference defaults on 160^3 in the 16-bit modes against the reference's own
-    output: fp16 storage meets north_star's 1e-3; bf16 (8 significant bits) is
-    reported and held to 1e-2."""
+    output: fp16 storage (the mode bench.py runs) meets north_star's 1e-3 on the
+    maximum; bf16 (8 significant bits) is held to 4e-3."""
     from aind_exaspim_neuron_segmentation_amd import inference
 
     g = golden("g6_default_160.npz")

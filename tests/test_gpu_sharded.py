@@ -19,7 +19,9 @@ from aind_exaspim_neuron_segmentation_amd.utils import synthetic
 pytestmark = pytest.mark.gpu
 
 GSHAPE = (104, 88, 56)
-KW = dict(patch_shape=(32, 32, 32), overlap=(8, 8, 8), trim=4)
+# overlap 16, trim 4: stride 16, trimmed outputs of 24 -> 8-voxel partial-sum bands
+# really cross the rank faces (with overlap 8 the trimmed outputs would tile exactly)
+KW = dict(patch_shape=(32, 32, 32), overlap=(16, 16, 16), trim=4)
 
 
 def _model(dev):

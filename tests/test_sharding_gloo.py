@@ -1,5 +1,7 @@
 """
-Multi-process tests of the sharding layer on CPU (gloo, world sizes 2 and 4):
+Multi-process tests of the sharding layer on CPU (gloo, world sizes 2, 4 and 8;
+one geometry whose trimmed outputs tile exactly and one with 8-voxel overlap
+bands that really travel between ranks):
 partition of the global patch grid, input halo exchange, histogram reduction
 and output band exchange. The device kernels are replaced by their numpy
 restatements so the N > 1 logic is covered without a GPU.
@@ -18,8 +20,11 @@ from aind_exaspim_neuron_segmentation_amd import inference, sharding
 from aind_exaspim_neuron_segmentation_amd.utils import synthetic
 
 GSHAPE = (104, 88, 56)
-PATCH, OVERLAP, TRIM = (32, 32, 32), (8, 8, 8), 4
+PATCH, TRIM = (32, 32, 32), 4
 CHANNELS = 2
+# overlap 8: stride 24 = trimmed output size, no overlap bands (pure partition);
+# overlap 16: stride 16, every trimmed output reaches 8 voxels into the next patch
+OVERLAPS = {"tiling": (8, 8, 8), "bands": (16, 16, 16)}
 
 
 def fake_patch_output(start):
@@ -41,8 +46,8 @@ def accumulate(accum, origin, starts, gshape):
         accum[(slice(None),) + dst] += pred[(slice(None),) + src]
 
 
-def expected_result():
-    plan = inference.SlidingWindow(GSHAPE, PATCH, OVERLAP, TRIM)
+def expected_result(overlap):
+    plan = inference.SlidingWindow(GSHAPE, PATCH, overlap, TRIM)
     accum = np.zeros((CHANNELS,) + GSHAPE, np.float32)
     accumulate(accum, (0, 0, 0), plan.starts(), GSHAPE)
     wgt = np.zeros((1,) + GSHAPE, np.float32)
@@ -54,14 +59,14 @@ def expected_result():
     return accum, wgt
 
 
-def _worker(rank, world, port, failures):
+def _worker(rank, world, port, failures, overlap):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.set_num_threads(1)
         group = dist.group.WORLD
-        plan = inference.SlidingWindow(GSHAPE, PATCH, OVERLAP, TRIM)
+        plan = inference.SlidingWindow(GSHAPE, PATCH, overlap, TRIM)
         grid = sharding.rank_grid(world)
         shard = sharding.Shard(plan, grid, rank)
         gvol = synthetic.synth_volume(GSHAPE, seed=3)
@@ -95,8 +100,11 @@ def _worker(rank, world, port, failures):
         accum = np.zeros((CHANNELS,) + shard.accum_dims, np.float32)
         accumulate(accum, shard.accum_origin, shard.starts, GSHAPE)
         accum_t = torch.from_numpy(accum)
+        if overlap[0] > 8 and shard.neighbour(1, 0) is not None:
+            lo, hi = shard.band_box(0)
+            assert hi[0] - lo[0] >= 8        # a real band leaves this rank
         sharding.exchange_output_bands(accum_t, shard, group)
-        want, wgt = expected_result()
+        want, wgt = expected_result(overlap)
         own = tuple(slice(a, b) for a, b in zip(shard.own_lo, shard.own_hi))
         got_own = sharding.owned_result(accum_t, shard).numpy()
         np.testing.assert_allclose(got_own, want[(slice(None),) + own], rtol=0, atol=2e-6)
@@ -121,12 +129,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_pipeline_gloo(world):
+@pytest.mark.parametrize("world,geometry", [(2, "tiling"), (4, "tiling"), (2, "bands"), (4, "bands"),
+                                            (8, "bands")])
+def test_sharded_pipeline_gloo(world, geometry):
+    """world 8 = the 4 x 2 grid of an 8-GPU node: interior z ranks send and receive
+    in the same phase, corner sums are forwarded z first, then y."""
     ctx = mp.get_context("spawn")
     failures = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, failures)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, failures, OVERLAPS[geometry]))
+             for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -156,3 +168,16 @@ def test_rank_grid_and_shard_geometry():
     assert all(len(s.starts) == 8192 for s in shards)
     with pytest.raises(ValueError):
         sharding.Shard(inference.SlidingWindow((96,) * 3, (96,) * 3, (32,) * 3, 8), (2, 1), 0)
+
+
+def test_shard_rejects_bands_wider_than_the_next_ranks_region():
+    """exchange_output_bands hands a band one rank forward per axis; a band wider than
+    the next rank's owned extent would have to travel two ranks. Such geometries are
+    refused (the defaults, band 16 < stride 64, are far from it)."""
+    plan = inference.SlidingWindow((200, 120, 64), (64,) * 3, (48,) * 3, 4)   # band 40, stride 16
+    with pytest.raises(ValueError, match="overlap band"):
+        sharding.Shard(plan, (4, 2), 0)
+    sharding.Shard(plan, (1, 1), 0)                      # a single rank has no bands
+    # 13 starts over 4 ranks -> 3 starts x 16 = 48 >= 40 on every interior rank
+    ok = inference.SlidingWindow((264, 120, 64), (64,) * 3, (48,) * 3, 4)
+    sharding.Shard(ok, (4, 1), 1)

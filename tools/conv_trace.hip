@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&partial, pbytes));
     exaspim::ConvArgs a{};
     a.src_a = a_dev; a.src_b = b_dev; a.ca = ca; a.cb = cb; a.weights = w_dev; a.bias = bias;
-    a.partial = partial; a.partial_bytes = pbytes;
+    a.partial = partial; a.partial_patch_bytes = pbytes / n;
     a.dst = dst; a.cout = cout; a.n = n; a.d = a.h = a.w = edge; a.slope = 0.01f;
     if (exaspim::g_variant != 0) {   // the variant must reproduce the library kernel bit for bit
         const int v = exaspim::g_variant;
