@@ -37,6 +37,31 @@ def get_patch_slices(start, patch_shape, img_shape):
     )
 
 
+def is_contained(voxel, shape, buffer=0):
+    """
+    Checks whether a voxel is within bounds of a given shape, considering a
+    buffer (img_util.py:451-474): the test the reference's validation tiling
+    applies to the centres of the zero-overlap patch grid
+    (data_handling.py:402-413).
+
+    Parameters
+    ----------
+    voxel : Tuple[int]
+        Voxel coordinates to be checked.
+    shape : Tuple[int]
+        Shape of the image volume.
+    buffer : int, optional
+        Number of voxels to pad the bounds by. Default is 0.
+
+    Returns
+    -------
+    bool
+        True if voxel - buffer and voxel + buffer lie inside the volume on
+        every axis.
+    """
+    return all(0 <= v - buffer and v + buffer < s for v, s in zip(voxel, shape))
+
+
 def reflect_index(j, n):
     """
     Source index inside a length-n axis for position j of its high-side

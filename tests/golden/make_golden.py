@@ -277,12 +277,33 @@ def g7_conv_transpose_variant():
          pred_sub=pred[:, ::2, ::2, ::2].copy())
 
 
+def g8_validation_tiling():
+    """The deterministic validation tiling of the reference's trainer
+    (data_handling.py:402-413: generate_patch_starts with zero overlap, patch
+    centres, img_util.is_contained with a 64-voxel buffer), produced with the
+    reference's own two helpers."""
+    out = {}
+    cases = [((500, 420, 640), (96, 96, 96)), ((192, 192, 192), (96, 96, 96)),
+             ((330, 300, 270), (64, 64, 64))]
+    for i, (vol, ps) in enumerate(cases):
+        shape5 = (1, 1) + vol
+        starts = list(ref_inf.generate_patch_starts(shape5, ps, (0, 0, 0)))
+        centers = [[v + s // 2 for v, s in zip(st, ps)] for st in starts]
+        kept = [c for c in centers if ref_img.is_contained(c, vol, buffer=64)]
+        out[f"case{i}_vol"] = np.array(vol)
+        out[f"case{i}_patch"] = np.array(ps)
+        out[f"case{i}_starts"] = np.array(starts, dtype=np.int64).reshape(-1, 3)
+        out[f"case{i}_centers_kept"] = np.array(kept, dtype=np.int64).reshape(-1, 3)
+    out["n_cases"] = np.array(len(cases))
+    save("g8_validation_tiling.npz", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g2b", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g2b", "g3", "g4", "g5", "g6", "g7", "g8"]
     table = dict(g1=g1_patch_starts, g2=g2_normalize, g2b=g2b_padding,
                  g3=g3_tiny_predict, g4=g4_single_patch,
                  g5=g5_fullwidth_small_patches, g6=g6_default_config,
-                 g7=g7_conv_transpose_variant)
+                 g7=g7_conv_transpose_variant, g8=g8_validation_tiling)
     for w in which:
         table[w]()

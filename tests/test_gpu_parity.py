@@ -220,6 +220,38 @@ def test_model_in_a_validation_loop(dev, oracle):
     assert not bool(differ.any())
 
 
+def test_validation_tiling_loop(dev, oracle, golden):
+    """ValidateDataset's deterministic tiling (data_handling.py:384-418) feeding the
+    trainer's validate_step (train.py:159-198): zero-overlap patch grid -> centres kept
+    by is_contained(buffer=64) (checked against the reference's own helpers, golden g8)
+    -> 64^3 patches cut around the centres -> batches through the HIP-backed module under
+    no_grad, as the DataLoader loop does; logits against the CPU oracle on the same tiles."""
+    from aind_exaspim_neuron_segmentation_amd import inference
+    from aind_exaspim_neuron_segmentation_amd.utils import img_util
+
+    g = golden("g8_validation_tiling.npz")
+    vol_shape = tuple(int(v) for v in g["case2_vol"])       # (330, 300, 270), 64^3 tiles
+    ps = tuple(int(v) for v in g["case2_patch"])
+    starts = inference.generate_patch_starts((1, 1) + vol_shape, ps, (0, 0, 0))
+    centers = [tuple(v + s // 2 for v, s in zip(st, ps)) for st in starts]
+    centers = [c for c in centers if img_util.is_contained(c, vol_shape, buffer=64)]
+    np.testing.assert_array_equal(np.array(centers), g["case2_centers_kept"])
+    img = oracle.normalize(np.minimum(synthetic.synth_volume(vol_shape, seed=77), 300), percentiles=(1, 99.5))
+    tiles = np.stack([img[tuple(slice(c - p // 2, c + p // 2) for c, p in zip(ctr, ps))]
+                      for ctr in centers[:6]])[:, None].astype(np.float32)
+    model, sd = make_model(dev, out_channels=3, seed=6)
+    model.eval()
+    outs = []
+    with torch.no_grad():
+        for i in range(0, len(tiles), 4):                   # DataLoader batches of 4
+            outs.append(model(torch.from_numpy(tiles[i:i + 4]).to("cuda", dtype=torch.float)).cpu())
+    got = torch.cat(outs).numpy()
+    want = oracle.unet_forward(torch.from_numpy(tiles), oracle.OracleModel(sd).sd).numpy()
+    err = np.abs(got - want).max()
+    print(f"validation tiling loop, {len(tiles)} tiles of {ps}: max|diff| = {err:.3e}")
+    assert err < 1e-4
+
+
 def test_unet_rejects_bad_inputs(dev):
     model, _ = make_model(dev)
     with pytest.raises(RuntimeError, match="Sizes of tensors must match"):

@@ -252,3 +252,23 @@ def test_reflect_index_matches_numpy_pad():
             want = np.pad(a, (0, p), mode="reflect")
             got = [img_util.reflect_index(j, n) for j in range(n + p)]
             np.testing.assert_array_equal(got, want)
+
+
+def test_validation_tiling_matches_reference_golden(golden):
+    """generate_patch_starts with zero overlap + patch centres + is_contained(buffer=64):
+    the tiling ValidateDataset builds its examples from (data_handling.py:402-413), against
+    centres produced by the reference's own helpers."""
+    from aind_exaspim_neuron_segmentation_amd import inference
+    from aind_exaspim_neuron_segmentation_amd.utils import img_util
+
+    g = golden("g8_validation_tiling.npz")
+    for i in range(int(g["n_cases"])):
+        vol = tuple(int(v) for v in g[f"case{i}_vol"])
+        ps = tuple(int(v) for v in g[f"case{i}_patch"])
+        starts = list(inference.generate_patch_starts((1, 1) + vol, ps, (0, 0, 0)))
+        np.testing.assert_array_equal(np.array(starts, dtype=np.int64).reshape(-1, 3), g[f"case{i}_starts"])
+        assert inference.count_patches((1, 1) + vol, ps, (0, 0, 0)) == len(starts)
+        centers = [[v + s // 2 for v, s in zip(st, ps)] for st in starts]
+        kept = [c for c in centers if img_util.is_contained(c, vol, buffer=64)]
+        np.testing.assert_array_equal(np.array(kept, dtype=np.int64).reshape(-1, 3),
+                                      g[f"case{i}_centers_kept"])

@@ -1,21 +1,33 @@
+"""Host-array-to-host-array rate of predict() and its phases (run on the GPU box).
+usage: python tools/host_rate.py [edge] [dtype] [copy_threads]"""
 import sys, time
-sys.path.insert(0, '.')
 import numpy as np, torch
+sys.path.insert(0, ".")
 from aind_exaspim_neuron_segmentation_amd import inference
 from aind_exaspim_neuron_segmentation_amd.machine_learning.unet3d import UNet3D
 from aind_exaspim_neuron_segmentation_amd.utils import synthetic
-dev = torch.device('cuda:0')
+
+edge = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+cdt = sys.argv[2] if len(sys.argv) > 2 else "fp16"
+threads = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 sd = synthetic.synth_state_dict(3, 1, seed=1)
-model = UNet3D(output_channels=3, compute_dtype='bf16')
-model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
-model = model.to(dev).eval()
-vol = synthetic.synth_volume((512, 512, 512), seed=5)
-inference.predict(vol[:160, :160, :160], model, verbose=False)  # warm-up
-for rep in range(2):
-    torch.cuda.synchronize(); t0 = time.time()
-    out = inference.predict(vol, model, verbose=False)
-    t1 = time.time()
-    torch.cuda.synchronize(); t2 = time.time()
-    dv = inference.predict(vol, model, verbose=False, return_device_tensor=True)
-    torch.cuda.synchronize(); t3 = time.time()
-    print(f"512^3 host->host {t1 - t0:.3f} s ({vol.size / (t1 - t0):.3e} vox/s), host->device result {t3 - t2:.3f} s, out {out.dtype} {out.shape}")
+m = UNet3D(output_channels=3, compute_dtype=cdt)
+m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+m.to("cuda").eval()
+vol = np.random.default_rng(0).integers(0, 2000, (edge,) * 3, dtype=np.uint16)
+for it in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    out = inference.predict(vol, m, verbose=False, return_device_tensor=True)
+    torch.cuda.synchronize(); t_dev = time.perf_counter() - t0
+    del out
+    tm = {}
+    t0 = time.perf_counter()
+    out = inference.predict_streaming(vol, m, verbose=False, copy_threads=threads, timings=tm)
+    t_host = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    out2 = inference.predict_streaming(vol, m, verbose=False, copy_threads=threads)
+    t_host2 = time.perf_counter() - t0
+    print(f"{edge}^3 {cdt}: device-resident {t_dev:.3f} s ({edge**3/t_dev:.3e} vox/s) | host->host "
+          f"{t_host2:.3f} s ({edge**3/t_host2:.3e} vox/s) | instrumented {t_host:.3f} s: "
+          + ", ".join(f"{k} {v:.3f}" for k, v in tm.items()), flush=True)
+    del out, out2
