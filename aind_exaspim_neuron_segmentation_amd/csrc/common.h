@@ -107,10 +107,13 @@ struct ConvArgs {
     float* head_out = nullptr;      // float (n, head_oc, d, h, w)
     int head_oc = 0;
     int head_sigmoid = 0;
-    // Output voxels closer than "margin" to a face of the patch are not needed by
-    // the caller (predict() trims them, inference.py:161-162): kernels that can
-    // skip them do (the z-column kernel drops whole tiles), the others ignore it.
-    int margin = 0;
+    // Region of output voxels the caller needs, [org, org + ext) per axis (z, y, x);
+    // ext = 0 means the whole patch. predict() trims the outputs of every patch
+    // (inference.py:161-162), so the last two convolutions only produce what survives:
+    // tiles start at org, whole tiles outside the region are never launched and
+    // stores are masked to it. Voxels outside the region are left untouched.
+    int org[3] = {0, 0, 0};
+    int ext[3] = {0, 0, 0};
     // Optional fused MaxPool3d(2) (unet3d.py:195) of this conv's output, written to
     // pool_dst as (n, cout, d/2, h/2, w/2) in the same layout (z-column kernel only:
     // ask conv_can_fuse_pool first); saves re-reading the whole skip tensor.
@@ -128,6 +131,14 @@ struct ConvArgs {
 };
 
 int launch_conv3x3x3(int dtype, const ConvArgs& a, hipStream_t stream);
+// Thin remainders of a region along y or x (at most 4 voxels thick) on 2-voxel-thick
+// tiles: what is left when the z-column kernel's 8 x 16 tiles cover only the multiple-of-
+// tile part of a trimmed region. 32-cout slices only.
+int launch_conv3x3x3_thin(int dtype, const ConvArgs& a, hipStream_t stream);
+// y / x extent of "ext" the z-column kernel should cover with whole tiles when the
+// remainder goes to launch_conv3x3x3_thin: the largest multiple of the tile if the
+// remainder is 1..4 voxels, else ext itself
+int conv_zcol_main_extent(int ext, int axis);
 bool conv_can_fuse_head(int cout, int w, int head_oc);
 bool conv_can_fuse_pool(int cout, int d, int h, int w);
 

@@ -185,7 +185,11 @@ __device__ __forceinline__ void store4<F16Tag>(void* dst, size_t off, float a, f
 //  * outputs go through LDS so every store instruction writes whole 16-byte
 //    pieces of consecutive voxel records (1 KiB contiguous per instruction when
 //    the tile row is 16 voxels of 32 channels).
-template <typename Tag, int TZ, int TY, int TX, int WAVES_M, int WAVES_N, int MT, int NT, int MINW, int PD>
+// ZORD: walk the 27 taps in the z-column kernel's order (in-plane tap outermost, dz
+// innermost) instead of dz-major, so that a voxel gets the same bits from either kernel
+// (the thin remainders of a region next to z-column tiles).
+template <typename Tag, int TZ, int TY, int TX, int WAVES_M, int WAVES_N, int MT, int NT, int MINW, int PD,
+          bool ZORD = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
     ConvArgs a, int tiles_z, int tiles_y, int tiles_x) {
     constexpr int G = Tag::kG;
@@ -233,7 +237,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
     const int ty = bid % tiles_y; bid /= tiles_y;
     const int tz = bid % tiles_z; bid /= tiles_z;
     const int nb = bid;
-    const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
+    const int z0 = a.org[0] + tz * TZ, y0 = a.org[1] + ty * TY, x0 = a.org[2] + tx * TX;
+    const int zend = a.org[0] + a.ext[0], yend = a.org[1] + a.ext[1], xend = a.org[2] + a.ext[2];
 
     const int ntiles = a.cout >> 5;
     const int ntile0 = (blockIdx.y * WAVES_N + wn) * NT;
@@ -324,15 +329,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
     for (int c = cbeg; c < nchunks; ++c) {
         const uint4* wp = static_cast<const uint4*>(a.weights) +
                           ((size_t)c * 27 * ntiles + ntile0) * 64 + lane;
+        // step t of the tap loop handles tap tap_of(t) = dz * 9 + dy * 3 + dx
+        constexpr auto tap_of = [](int t) { return ZORD ? (t % 3) * 9 + t / 3 : t; };
         uint4 wring[PD + 1][NT];
 #pragma unroll
         for (int t = 0; t < PD; ++t)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wring[t][nt] = wp[((size_t)t * ntiles + nt) * 64];
+            for (int nt = 0; nt < NT; ++nt) wring[t][nt] = wp[((size_t)tap_of(t) * ntiles + nt) * 64];
 
         uint4 xf[2][MT];
+        {
+            constexpr int t0 = tap_of(0);
+            constexpr int tapoff0 = ((t0 / 9) * HY + (t0 / 3) % 3) * HXS + t0 % 3;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) xf[0][mt] = lds[base[mt]];
+            for (int mt = 0; mt < MT; ++mt) xf[0][mt] = lds[base[mt] + tapoff0];
+        }
 
         const bool more = c + 1 < nchunks;
 #pragma unroll
@@ -340,11 +351,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
             if (t + PD < 27) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    wring[(t + PD) % (PD + 1)][nt] = wp[((size_t)(t + PD) * ntiles + nt) * 64];
+                    wring[(t + PD) % (PD + 1)][nt] = wp[((size_t)tap_of(t + PD) * ntiles + nt) * 64];
             }
             if (t == ISSUE_T && more) stage_load(c + 1);
             if (t + 1 < 27) {
-                const int tapoff = (((t + 1) / 9) * HY + ((t + 1) / 3) % 3) * HXS + (t + 1) % 3;
+                const int tn = tap_of(t + 1);
+                const int tapoff = ((tn / 9) * HY + (tn / 3) % 3) * HXS + tn % 3;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) xf[(t + 1) & 1][mt] = lds[base[mt] + tapoff];
             }
@@ -375,7 +387,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
             const int m = (wm * MT + mt) * 32 + r;
             const int z = m / (TY * TX), y = (m / TX) % TY, x = m % TX;
             const int gz = z0 + z, gy = y0 + y, gx = x0 + x;
-            if (m < TILE_VOX && gz < a.d && gy < a.h && gx < a.w) {
+            if (m < TILE_VOX && gz < zend && gy < yend && gx < xend) {
                 float* rec = part + (((size_t)gz * a.h + gy) * a.w + gx) * a.cout;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
@@ -417,7 +429,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
         const int m = (wm * MT + mt) * 32 + vv;
         const int z = m / (TY * TX), y = (m / TX) % TY, x = m % TX;
         const int gz = z0 + z, gy = y0 + y, gx = x0 + x;
-        const bool ok = m < TILE_VOX && gz < a.d && gy < a.h && gx < a.w;
+        const bool ok = m < TILE_VOX && gz < zend && gy < yend && gx < xend;
         const size_t vox = ((size_t)gz * a.h + gy) * a.w + gx;
         char* const dplane = static_cast<char*>(a.dst) +
                              ((size_t)nb * (a.cout / KC) + ntile0 * (32 / KC)) * patch_vox * 32;
@@ -521,9 +533,9 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
     };
     auto tile_at = [&](int id) {
         Tile t;
-        t.x0 = a.margin + (id % tiles_x) * TX; id /= tiles_x;
-        t.y0 = a.margin + (id % tiles_y) * TY; id /= tiles_y;
-        t.z0 = a.margin + (id % tiles_z) * TZ; id /= tiles_z;
+        t.x0 = a.org[2] + (id % tiles_x) * TX; id /= tiles_x;
+        t.y0 = a.org[1] + (id % tiles_y) * TY; id /= tiles_y;
+        t.z0 = a.org[0] + (id % tiles_z) * TZ; id /= tiles_z;
         t.nb = id;
         return t;
     };
@@ -760,7 +772,7 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
 #pragma unroll
             for (int z = 0; z < TZ; ++z) {
                 const int gz = cur.z0 + z;
-                const bool ok = gz < a.d - a.margin && gy < a.h - a.margin && gx < a.w - a.margin;
+                const bool ok = gz < a.org[0] + a.ext[0] && gy < a.org[1] + a.ext[1] && gx < a.org[2] + a.ext[2];
 #pragma unroll
                 for (int o = 0; o < HEAD; ++o) {
                     float t = part[z][o] + __shfl_xor(part[z][o], 32) + head_s[HEAD * 32 + o];
@@ -810,7 +822,7 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
 #pragma unroll
                 for (int z = zb; z < zb + TB && z < TZ; ++z) {
                     const int gz = cur.z0 + z;
-                    const bool ok = gz < a.d - a.margin && ogy < a.h - a.margin && ogx < a.w - a.margin;
+                    const bool ok = gz < a.org[0] + a.ext[0] && ogy < a.org[1] + a.ext[1] && ogx < a.org[2] + a.ext[2];
                     const size_t vox = ((size_t)gz * a.h + ogy) * a.w + ogx;
 #pragma unroll
                     for (int ck = 0; ck < CPT; ++ck) {
@@ -884,9 +896,8 @@ static int resident_workgroups(int per_cu) {
 
 template <typename Tag, int TZ, int TY, int TX, int MINW, int D, int HEAD = 0, bool POOL = false>
 static int launch_zpipe(const ConvArgs& a, hipStream_t stream) {
-    // tiles cover the voxels the caller needs, [margin, size - margin) on every axis
-    const int m2 = 2 * a.margin;
-    const int tz = (a.d - m2 + TZ - 1) / TZ, ty = (a.h - m2 + TY - 1) / TY, tx = (a.w - m2 + TX - 1) / TX;
+    // tiles cover the voxels the caller needs, [org, org + ext) on every axis
+    const int tz = (a.ext[0] + TZ - 1) / TZ, ty = (a.ext[1] + TY - 1) / TY, tx = (a.ext[2] + TX - 1) / TX;
     const long long blocks = (long long)tz * ty * tx * a.n;
     if (blocks <= 0 || blocks > 0x7fffffffLL) {
         set_error("conv: grid of %lld blocks out of range", blocks);
@@ -937,19 +948,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // ---- host side: pick a tile configuration per layer -----------------------
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-template <typename Tag, int TZ, int TY, int TX, int WAVES_M, int WAVES_N, int MT, int NT, int MINW, int PD = 3>
+template <typename Tag, int TZ, int TY, int TX, int WAVES_M, int WAVES_N, int MT, int NT, int MINW, int PD = 3,
+          bool ZORD = false>
 static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
     constexpr int NWG = WAVES_N * NT * 32;
     if (a.cout % NWG != 0) {
         set_error("conv: cout %d not a multiple of the %d-channel tile", a.cout, NWG);
         return EXASPIM_E_INVALID;
     }
-    const int tz = cdiv(a.d, TZ), ty = cdiv(a.h, TY), tx = cdiv(a.w, TX);
+    const int tz = cdiv(a.ext[0], TZ), ty = cdiv(a.ext[1], TY), tx = cdiv(a.ext[2], TX);
     const long long blocks = (long long)tz * ty * tx * a.n;
     if (blocks <= 0 || blocks > 0x7fffffffLL) {
         set_error("conv: grid of %lld blocks out of range", blocks);
         return EXASPIM_E_INVALID;
     }
+    const bool whole = a.ext[0] == a.d && a.ext[1] == a.h && a.ext[2] == a.w;
     // Split-K when a launch of a nominal batch (16 patches) cannot give every CU two
     // workgroups: up to 4 ranges of chunks (one at least per range), if the scratch holds
     // the partial sums. The split changes the order in which a voxel's products are
@@ -963,7 +976,7 @@ static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
     const int nchunks = (a.ca + a.cb) / (2 * Tag::kG);
     const size_t patch_vox_all = (size_t)a.d * a.h * a.w;
     const size_t nvox_all = (size_t)a.n * patch_vox_all;
-    if (a.partial && !a.head_out && !a.pool_dst && wgs * 2 <= resident_workgroups(2)) {
+    if (a.partial && whole && !a.head_out && !a.pool_dst && wgs * 2 <= resident_workgroups(2)) {
         int ks = (int)(resident_workgroups(2) / wgs);
         if (ks > 4) ks = 4;
         if (ks > nchunks) ks = nchunks;
@@ -971,7 +984,7 @@ static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
         b.ksplit = ks;
     }
     dim3 grid((unsigned)blocks, a.cout / NWG, b.ksplit);
-    conv3x3x3_t14<Tag, TZ, TY, TX, WAVES_M, WAVES_N, MT, NT, MINW, PD>
+    conv3x3x3_t14<Tag, TZ, TY, TX, WAVES_M, WAVES_N, MT, NT, MINW, PD, ZORD>
         <<<grid, WAVES_M * WAVES_N * 64, 0, stream>>>(b, tz, ty, tx);
     EXA_CHECK_HIP(hipGetLastError());
     if (b.ksplit > 1) {
@@ -1050,15 +1063,34 @@ bool conv_can_fuse_head(int cout, int w, int head_oc) {
     return cout == 32 && w >= 16 && w % 16 == 0 && head_oc >= 1 && head_oc <= 4;
 }
 
-int launch_conv3x3x3(int dtype, const ConvArgs& a, hipStream_t stream) {
+// ext = 0 stands for the whole axis; the region must lie inside the patch
+static int resolve_region(ConvArgs& a) {
+    const int dims[3] = {a.d, a.h, a.w};
+    for (int i = 0; i < 3; ++i) {
+        if (a.ext[i] == 0 && a.org[i] == 0) a.ext[i] = dims[i];
+        EXA_CHECK_ARG(a.org[i] >= 0 && a.ext[i] > 0 && a.org[i] + a.ext[i] <= dims[i],
+                      "conv: region [%d, %d) outside axis %d of a %dx%dx%d patch", a.org[i],
+                      a.org[i] + a.ext[i], i, a.d, a.h, a.w);
+    }
+    return EXASPIM_OK;
+}
+
+int conv_zcol_main_extent(int ext, int axis) {
+    const int tile = axis == 1 ? 8 : 16;   // the z-column kernel's TY / TX
+    const int rem = ext % tile;
+    return (axis != 0 && ext > tile && rem >= 1 && rem <= 4) ? ext - rem : ext;
+}
+
+int launch_conv3x3x3(int dtype, const ConvArgs& a_in, hipStream_t stream) {
+    ConvArgs a = a_in;
     const int kc = dtype == EXASPIM_DT_F32 ? 8 : 16;
     EXA_CHECK_ARG(a.ca % kc == 0 && a.cb % kc == 0 && a.cout % 32 == 0 && a.ca > 0,
                   "conv: channels (%d,%d)->%d not padded", a.ca, a.cb, a.cout);
     EXA_CHECK_ARG(a.n > 0 && a.d > 0 && a.h > 0 && a.w > 0, "conv: empty input");
     EXA_CHECK_ARG(a.slope >= 0.f && a.slope <= 1.f, "conv: LeakyReLU slope %g outside [0, 1]", a.slope);
-    EXA_CHECK_ARG(a.margin >= 0 && 2 * a.margin < a.d && 2 * a.margin < a.h && 2 * a.margin < a.w,
-                  "conv: margin %d leaves nothing of a %dx%dx%d patch", a.margin, a.d, a.h, a.w);
-    EXA_CHECK_ARG(!a.pool_dst || (conv_can_fuse_pool(a.cout, a.d, a.h, a.w) && !a.head_out && a.margin == 0),
+    if (int rc = resolve_region(a)) return rc;
+    const bool whole = a.ext[0] == a.d && a.ext[1] == a.h && a.ext[2] == a.w;
+    EXA_CHECK_ARG(!a.pool_dst || (conv_can_fuse_pool(a.cout, a.d, a.h, a.w) && !a.head_out && whole),
                   "conv: fused max-pool needs a 32-cout-slice layer on an even, untrimmed patch");
     EXA_CHECK_ARG(!a.head_out || conv_can_fuse_head(a.cout, a.w, a.head_oc),
                   "conv: fused head needs cout 32, w %% 16 == 0, 1..4 outputs");
@@ -1071,6 +1103,32 @@ int launch_conv3x3x3(int dtype, const ConvArgs& a, hipStream_t stream) {
         case EXASPIM_DT_F32: return launch_typed<F32Tag>(a, stream);
         case EXASPIM_DT_BF16: return launch_typed<BF16Tag>(a, stream);
         case EXASPIM_DT_F16: return launch_typed<F16Tag>(a, stream);
+    }
+    set_error("conv: unknown dtype %d", dtype);
+    return EXASPIM_E_INVALID;
+}
+
+template <typename Tag>
+static int launch_thin_typed(const ConvArgs& a, hipStream_t stream) {
+    // 2-voxel-thick tiles: thin along y (4 x 2 x 16) or along x (4 x 16 x 2); four waves,
+    // one 32-voxel group each
+    if (a.ext[1] <= a.ext[2]) return launch_cfg<Tag, 4, 2, 16, 4, 1, 1, 1, 2, 3, true>(a, stream);
+    return launch_cfg<Tag, 4, 16, 2, 4, 1, 1, 1, 2, 3, true>(a, stream);
+}
+
+int launch_conv3x3x3_thin(int dtype, const ConvArgs& a_in, hipStream_t stream) {
+    ConvArgs a = a_in;
+    const int kc = dtype == EXASPIM_DT_F32 ? 8 : 16;
+    EXA_CHECK_ARG(a.ca % kc == 0 && a.cb % kc == 0 && a.cout % 32 == 0 && a.ca > 0,
+                  "conv: channels (%d,%d)->%d not padded", a.ca, a.cb, a.cout);
+    EXA_CHECK_ARG(a.n > 0 && a.d > 0 && a.h > 0 && a.w > 0, "conv: empty input");
+    EXA_CHECK_ARG(!a.pool_dst && !a.head_out, "conv: thin tiles have no fused pool or head");
+    if (int rc = resolve_region(a)) return rc;
+    a.partial = nullptr;   // no split-K on a partial region
+    switch (dtype) {
+        case EXASPIM_DT_F32: return launch_thin_typed<F32Tag>(a, stream);
+        case EXASPIM_DT_BF16: return launch_thin_typed<BF16Tag>(a, stream);
+        case EXASPIM_DT_F16: return launch_thin_typed<F16Tag>(a, stream);
     }
     set_error("conv: unknown dtype %d", dtype);
     return EXASPIM_E_INVALID;

@@ -110,8 +110,24 @@ static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, in
         a.partial = reinterpret_cast<float*>(base + ws.xpad);
         a.partial_patch_bytes = (size_t)(d + 2) * (h + 2) * (w + 2) * sizeof(float);
         if (idx == 0 && fuse_pool) a.pool_dst = A(1);
-        if (trimmed && idx == kNumMfmaConvs - 1) a.margin = trim;
-        if (trimmed && idx == kNumMfmaConvs - 2) a.margin = trim - 1;
+        // up4.3 produces [trim, size - trim), up4.0 one voxel more on every face
+        const int margin = !trimmed ? 0 : idx == kNumMfmaConvs - 1 ? trim : idx == kNumMfmaConvs - 2 ? trim - 1 : 0;
+        const int full[3] = {d >> l, h >> l, w >> l};
+        for (int i = 0; i < 3; ++i) {
+            a.org[i] = margin;
+            a.ext[i] = full[i] - 2 * margin;
+        }
+        // When the region is a few voxels more than whole z-column tiles along y or x (82 =
+        // 10 x 8 + 2 = 5 x 16 + 2 for the default patch), the z-column kernel covers the whole
+        // tiles and two launches on 2-voxel-thick tiles the rest, instead of a ninth row and a
+        // sixth column of mostly masked 8 x 16 tiles (924 tiles for 718 tiles' worth of voxels).
+        int rem_y = 0, rem_x = 0;
+        if (margin > 0 && L.cout % 64 != 0 && full[2] % 16 == 0) {
+            rem_y = a.ext[1] - conv_zcol_main_extent(a.ext[1], 1);
+            rem_x = a.ext[2] - conv_zcol_main_extent(a.ext[2], 2);
+            a.ext[1] -= rem_y;
+            a.ext[2] -= rem_x;
+        }
         if (idx == kNumMfmaConvs - 1 && fuse_head) {
             a.head_w = reinterpret_cast<const float*>(e->packed + p.head_w_off);
             a.head_b = reinterpret_cast<const float*>(e->packed + p.head_b_off);
@@ -132,12 +148,23 @@ static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, in
             slot = t->next;
             EXA_CHECK_HIP(hipEventRecord(t->start[slot], stream));
         }
-        const int r = launch_conv3x3x3(dt, a, stream);
+        int r = launch_conv3x3x3(dt, a, stream);
         if (timed && r == EXASPIM_OK) {
             EXA_CHECK_HIP(hipEventRecord(t->stop[slot], stream));
             t->layer[slot] = idx;
             t->next = (slot + 1) % LayerTimer::kRing;
             t->used++;
+        }
+        if (r == EXASPIM_OK && rem_y > 0) {      // rows [org_y + main, org_y + main + rem_y), every x of the region
+            ConvArgs b = a;
+            b.org[1] = a.org[1] + a.ext[1]; b.ext[1] = rem_y;
+            b.ext[2] = a.ext[2] + rem_x;
+            r = launch_conv3x3x3_thin(dt, b, stream);
+        }
+        if (r == EXASPIM_OK && rem_x > 0) {      // columns beyond the whole tiles, rows of the main part
+            ConvArgs b = a;
+            b.org[2] = a.org[2] + a.ext[2]; b.ext[2] = rem_x;
+            r = launch_conv3x3x3_thin(dt, b, stream);
         }
         return r;
     };

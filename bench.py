@@ -81,6 +81,13 @@ def parse_args():
     return p.parse_args()
 
 
+def zcol_main(ext, tile):
+    """Extent the z-column kernel covers with whole tiles (csrc/conv3d.hip:
+    conv_zcol_main_extent): a remainder of 1..4 voxels goes to thin-tile launches."""
+    rem = ext % tile
+    return ext - rem if ext > tile and 1 <= rem <= 4 else ext
+
+
 def launch_ranks(args):
     """Parent of an N-rank run: spawns the ranks and never initialises the GPU."""
     with socket.socket() as s:
@@ -303,9 +310,12 @@ def main():
         flops = 0.0
         for b, cin, cout, edge in DOMINANT_CONVS:
             # up4.0 (bit 15) only computes what up4.3 reads of the voxels predict() keeps:
-            # trim - 1 voxels less on every face (exaspim_unet_forward_trimmed)
+            # trim - 1 voxels less on every face (exaspim_unet_forward_trimmed) = 82^3; of
+            # that the timed z-column launch covers the whole 8 x 16 (y, x) tiles, 82 x 80 x 80
+            # (the two 2-voxel-thick remainders run as separate, untimed thin-tile launches)
             need = edge - 2 * (TRIM - 1) if b == 15 else edge
-            flops += cnt[b] * 2.0 * 27 * cin * cout * args.batch * need ** 3
+            vox = need * zcol_main(need, 8) * zcol_main(need, 16) if b == 15 else need ** 3
+            flops += cnt[b] * 2.0 * 27 * cin * cout * args.batch * vox
         # the last batch of a step may be short; scale by the real patch count
         patches_per_step = len(shard.starts)
         full_batches = -(-patches_per_step // args.batch)
