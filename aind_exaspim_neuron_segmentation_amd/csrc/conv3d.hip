@@ -1112,8 +1112,9 @@ template <typename Tag>
 static int launch_thin_typed(const ConvArgs& a, hipStream_t stream) {
     // 2-voxel-thick tiles: thin along y (4 x 2 x 16) or along x (4 x 16 x 2); four waves,
     // one 32-voxel group each
-    if (a.ext[1] <= a.ext[2]) return launch_cfg<Tag, 4, 2, 16, 4, 1, 1, 1, 2, 3, true>(a, stream);
-    return launch_cfg<Tag, 4, 16, 2, 4, 1, 1, 1, 2, 3, true>(a, stream);
+    // (four workgroups per CU: a workgroup is four short chunk steps, mostly load latency)
+    if (a.ext[1] <= a.ext[2]) return launch_cfg<Tag, 4, 2, 16, 4, 1, 1, 1, 4, 3, true>(a, stream);
+    return launch_cfg<Tag, 4, 16, 2, 4, 1, 1, 1, 4, 3, true>(a, stream);
 }
 
 int launch_conv3x3x3_thin(int dtype, const ConvArgs& a_in, hipStream_t stream) {

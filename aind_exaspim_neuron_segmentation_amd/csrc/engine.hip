@@ -122,7 +122,8 @@ static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, in
         // tiles and two launches on 2-voxel-thick tiles the rest, instead of a ninth row and a
         // sixth column of mostly masked 8 x 16 tiles (924 tiles for 718 tiles' worth of voxels).
         int rem_y = 0, rem_x = 0;
-        if (margin > 0 && L.cout % 64 != 0 && full[2] % 16 == 0) {
+        const bool has_head = idx == kNumMfmaConvs - 1 && fuse_head;   // the head runs on z-column tiles only
+        if (margin > 0 && !has_head && L.cout % 64 != 0 && full[2] % 16 == 0) {
             rem_y = a.ext[1] - conv_zcol_main_extent(a.ext[1], 1);
             rem_x = a.ext[2] - conv_zcol_main_extent(a.ext[2], 2);
             a.ext[1] -= rem_y;

@@ -13,6 +13,10 @@
 
 #include "common.h"
 
+// This file is compiled with -ffp-contract=off (Makefile): the interpolation coordinates
+// below must come out of a rounded product and a rounded difference like ATen's, and the
+// same in every inlined copy; every fused multiply-add these kernels want is written out.
+
 namespace exaspim {
 
 struct F32T {
@@ -506,113 +510,167 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const uint4* __restrict__
 // i1 = min(i0 + 1, in - 1). The three scales are computed on the host with the
 // same float division.
 __device__ __forceinline__ void lerp_coord(int o, int in, float scale, int& i0, int& i1, float& l1) {
+    // rounded product, then a rounded difference, as ATen computes them (no contraction
+    // into one fma: see the note on -ffp-contract=off at the top of the file)
     const float s = scale * (float)o;
     i0 = min((int)floorf(s), in - 1);
     i1 = min(i0 + 1, in - 1);
     l1 = fminf(fmaxf(s - (float)i0, 0.f), 1.f);
 }
 
-// Grid: x = (volume, pair of output planes), y = blocks of voxels of a plane. A thread
-// produces one voxel record (both 16-byte groups) of two consecutive output planes: their
-// z interpolation coordinates are scalar, they share the in-plane weights, and together
-// they touch three (at most four) source planes, each interpolated in-plane once --
-// torch's own nesting, d0 * (h0 * (w0 v000 + w1 v001) + h1 * (...)) + d1 * (...).
-// "row_magic" = floor(2^32 / row voxels) + 1 turns the row split into a multiply-high
-// (exact for the plane sizes the launcher admits).
+// A thread owns a pair of output rows at one x (one 16-byte channel group) and walks a
+// run of output planes, two at a time; lanes run along (x, group), so a store instruction
+// writes 1 KiB of consecutive voxel records. Along z and y two consecutive outputs read the
+// sources i0, i0 + 1 and, for the second one, possibly i0 + 2 (the source coordinate grows
+// by scale < 1/2 per output). The interpolation runs separably in torch's own nesting,
+// d0 * (h0 * (w0 v000 + w1 v001) + h1 * (...)) + d1 * (...): a source plane is interpolated
+// along x and y once (3 rows x 2 columns of 16-byte pieces, each converted to float once)
+// into the thread's two output rows and kept in registers for the 2-4 output planes that
+// blend it -- the last three source planes are live, a pair of output planes needs about
+// one new one. Per axis the first output of a pair is fma(w1, v[1], w0 * v[0]); the second
+// one takes (v[0], v[1]) or (v[1], v[2]) depending on whether its i0 moved on: it is
+// evaluated as fma(c2, v[2], fma(c1, v[1], c0 * v[0])) with (c0, c1, c2) = (w0, w1, 0) or
+// (0, w0, w1) -- the zero term adds nothing, so the value is the two-term expression bit for
+// bit and no lane ever selects between registers. Sources are taken at min(i0 + k, n - 1),
+// which is where torch's clamped i1 points when i0 is the last element.
+// Grid: x = (volume, run of kUpsZRun pairs of output planes), y = blocks of (row pair, x, group).
+constexpr int kUpsZRun = 12;
+#ifndef UPS_MINW
+#define UPS_MINW 3   // waves per SIMD the register allocation aims at (tools/layer_bench.hip)
+#endif
+
+struct LerpPair {
+    int s0, s1, s2;        // source indices i0, min(i0 + 1, n - 1), min(i0 + 2, n - 1) of the first output
+    float a0, a1;          // first output: a0 * v[0] + a1 * v[1]
+    float b0, b1, b2;      // second output (see above)
+};
+
+__device__ __forceinline__ LerpPair lerp_pair(int o, bool has_second, int in, float scale) {
+    int i0, i1, j0, j1;
+    float la, lb;
+    lerp_coord(o, in, scale, i0, i1, la);
+    lerp_coord(has_second ? o + 1 : o, in, scale, j0, j1, lb);
+    LerpPair p;
+    p.s0 = i0; p.s1 = min(i0 + 1, in - 1); p.s2 = min(i0 + 2, in - 1);
+    p.a0 = 1.f - la; p.a1 = la;
+    const bool moved = j0 != i0;   // j0 is i0 or i0 + 1
+    p.b0 = moved ? 0.f : 1.f - lb;
+    p.b1 = moved ? 1.f - lb : lb;
+    p.b2 = moved ? lb : 0.f;
+    return p;
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void upsample2_kernel(const uint4* __restrict__ src,
-                                                        uint4* __restrict__ dst, int d, int h,
-                                                        int w, unsigned row_magic, float sz,
-                                                        float sy, float sx, int margin) {
+__global__ __launch_bounds__(256, UPS_MINW) void upsample2_kernel(const uint4* __restrict__ src,
+                                                           uint4* __restrict__ dst, int d, int h,
+                                                           int w, float sz, float sy, float sx,
+                                                           int margin) {
     // output voxels closer than "margin" to a face are not needed by the caller
-    constexpr int cg = 2;  // 16-byte groups of a 32-byte record
-    constexpr int NF = T::kG;   // float pairs of a record (two groups)
+    constexpr int cg = 2;       // 16-byte groups of a 32-byte record
+    constexpr int NP = T::kG / 2;   // float pairs of a group
     typedef float f2 __attribute__((ext_vector_type(2)));
     const int od = d * 2, oh = h * 2, ow = w * 2;
-    const int nz = od - 2 * margin, ny = oh - 2 * margin, rowv = ow - 2 * margin;
-    const int nzp = (nz + 1) >> 1;
-    const unsigned i = blockIdx.y * blockDim.x + threadIdx.x;  // voxel inside the needed plane
-    if (i >= (unsigned)(ny * rowv)) return;
-    const int yy = (int)__umulhi(i, row_magic);
-    const int y = margin + yy, x = margin + ((int)i - yy * rowv);
-    const int nb = blockIdx.x / nzp, za = margin + 2 * (blockIdx.x - nb * nzp);
-    const bool has_b = za + 1 < od - margin;
-    int a0, a1, b0, b1, y0, y1, x0, x1;
-    float la, lb, ly, lx;
-    lerp_coord(za, d, sz, a0, a1, la);
-    lerp_coord(has_b ? za + 1 : za, d, sz, b0, b1, lb);
-    lerp_coord(y, h, sy, y0, y1, ly);
+    const int nz = od - 2 * margin, ny = oh - 2 * margin, nx = ow - 2 * margin;
+    const int nzp = (nz + 1) >> 1, nyp = (ny + 1) >> 1;
+    const int nruns = (nzp + kUpsZRun - 1) / kUpsZRun;
+    const unsigned item = blockIdx.y * blockDim.x + threadIdx.x;
+    if (item >= (unsigned)(nyp * nx * cg)) return;
+    const int g = item & 1;
+    const int yp = (int)(item >> 1) / nx, x = margin + (int)(item >> 1) - yp * nx;
+    const int nb = blockIdx.x / nruns, run = blockIdx.x - nb * nruns;
+    const int ya = margin + 2 * yp;
+    const bool has_yb = ya + 1 < oh - margin;
+    const LerpPair py = lerp_pair(ya, has_yb, h, sy);
+    int x0, x1;
+    float lx;
     lerp_coord(x, w, sx, x0, x1, lx);
-    const f2 wx0 = {1.f - lx, 1.f - lx}, wx1 = {lx, lx}, wy0 = {1.f - ly, 1.f - ly}, wy1 = {ly, ly};
-    const uint4* base = src + (size_t)nb * d * h * w * cg;
-    const int o00 = (y0 * w + x0) * cg, o01 = (y0 * w + x1) * cg, o10 = (y1 * w + x0) * cg,
-              o11 = (y1 * w + x1) * cg;
+    const f2 wx0 = {1.f - lx, 1.f - lx}, wx1 = {lx, lx};
+    const uint4* base = src + (size_t)nb * d * h * w * cg + g;
+    const int pos[3][2] = {{(py.s0 * w + x0) * cg, (py.s0 * w + x1) * cg},
+                           {(py.s1 * w + x0) * cg, (py.s1 * w + x1) * cg},
+                           {(py.s2 * w + x0) * cg, (py.s2 * w + x1) * cg}};
+    const float yA[3] = {py.a0, py.a1, 0.f}, yB[3] = {py.b0, py.b1, py.b2};
 
-    // in-plane interpolation of source plane zp (wave-uniform), both groups of the record
-    auto plane = [&](int zp, f2* p) {
-        const uint4* pl = base + (size_t)zp * h * w * cg;
+    // source plane -> this thread's two output rows (x and y interpolation)
+    auto load_plane = [&](int p, f2 (*q)[NP]) {
+        const uint4* plane = base + (size_t)p * h * w * cg;
 #pragma unroll
-        for (int g = 0; g < cg; ++g) {
-            float v00[T::kG], v01[T::kG], v10[T::kG], v11[T::kG];
-            T::unpack(pl[o00 + g], v00);
-            T::unpack(pl[o01 + g], v01);
-            T::unpack(pl[o10 + g], v10);
-            T::unpack(pl[o11 + g], v11);
+        for (int r = 0; r < 3; ++r) {
+            float v0[T::kG], v1[T::kG];
+            T::unpack(plane[pos[r][0]], v0);
+            T::unpack(plane[pos[r][1]], v1);
 #pragma unroll
-            for (int j = 0; j < T::kG / 2; ++j) {
-                const f2 r0 = __builtin_elementwise_fma(wx1, (f2){v01[2 * j], v01[2 * j + 1]},
-                                                        wx0 * (f2){v00[2 * j], v00[2 * j + 1]});
-                const f2 r1 = __builtin_elementwise_fma(wx1, (f2){v11[2 * j], v11[2 * j + 1]},
-                                                        wx0 * (f2){v10[2 * j], v10[2 * j + 1]});
-                p[g * (T::kG / 2) + j] = __builtin_elementwise_fma(wy1, r1, wy0 * r0);
+            for (int j = 0; j < NP; ++j) {
+                const f2 xr = __builtin_elementwise_fma(wx1, (f2){v1[2 * j], v1[2 * j + 1]},
+                                                        wx0 * (f2){v0[2 * j], v0[2 * j + 1]});
+                const f2 wa = {yA[r], yA[r]}, wb = {yB[r], yB[r]};
+                if (r == 0) {
+                    q[0][j] = wa * xr;
+                    q[1][j] = wb * xr;
+                } else {
+                    if (r == 1) q[0][j] = __builtin_elementwise_fma(wa, xr, q[0][j]);
+                    q[1][j] = __builtin_elementwise_fma(wb, xr, q[1][j]);
+                }
             }
         }
     };
-    auto store = [&](int z, const f2* p0, const f2* p1, float l) {
-        const f2 w0 = {1.f - l, 1.f - l}, w1 = {l, l};
-        uint4* rec = dst + ((((size_t)nb * od + z) * oh + y) * ow + x) * cg;
+    auto store = [&](int z, const f2 (*o)[NP]) {
 #pragma unroll
-        for (int g = 0; g < cg; ++g) {
+        for (int yy = 0; yy < 2; ++yy) {
+            if (yy == 1 && !has_yb) continue;
             float out[T::kG];
 #pragma unroll
-            for (int j = 0; j < T::kG / 2; ++j) {
-                const f2 v = __builtin_elementwise_fma(w1, p1[g * (T::kG / 2) + j], w0 * p0[g * (T::kG / 2) + j]);
-                out[2 * j] = v.x; out[2 * j + 1] = v.y;
-            }
-            rec[g] = T::pack(out);
+            for (int j = 0; j < NP; ++j) { out[2 * j] = o[yy][j].x; out[2 * j + 1] = o[yy][j].y; }
+            dst[((((size_t)nb * od + z) * oh + ya + yy) * ow + x) * cg + g] = T::pack(out);
         }
     };
 
-    f2 pa0[NF], pa1[NF];
-    plane(a0, pa0);
-    if (a1 != a0) plane(a1, pa1);
-    else {
+    // the last three interpolated source planes, q2 the newest (plane "top")
+    f2 q0[2][NP], q1[2][NP], q2[2][NP];
 #pragma unroll
-        for (int j = 0; j < NF; ++j) pa1[j] = pa0[j];
+    for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) q0[yy][j] = q1[yy][j] = q2[yy][j] = (f2){0.f, 0.f};
+    int top = -1;
+    const int pair_end = min(nzp, (run + 1) * kUpsZRun);
+    for (int pr = run * kUpsZRun; pr < pair_end; ++pr) {     // wave-uniform
+        const int za = margin + 2 * pr;
+        const bool has_zb = za + 1 < od - margin;
+        const LerpPair pz = lerp_pair(za, has_zb, d, sz);
+        const int need[3] = {pz.s0, pz.s1, pz.s2};           // non-decreasing, steps of 0 or 1
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (need[k] > top) {
+#pragma unroll
+                for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) { q0[yy][j] = q1[yy][j]; q1[yy][j] = q2[yy][j]; }
+                load_plane(need[k], q2);
+                top = need[k];
+            }
+        }
+        // top == s2; plane s0 sits (top - s0) slots back, s1 one in front of it (clamped to q2)
+        f2 oa[2][NP], ob[2][NP];
+        auto blend = [&](const f2 (*v0)[NP], const f2 (*v1)[NP], const f2 (*v2)[NP]) {
+#pragma unroll
+            for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    oa[yy][j] = __builtin_elementwise_fma((f2){pz.a1, pz.a1}, v1[yy][j],
+                                                          (f2){pz.a0, pz.a0} * v0[yy][j]);
+                    ob[yy][j] = __builtin_elementwise_fma(
+                        (f2){pz.b2, pz.b2}, v2[yy][j],
+                        __builtin_elementwise_fma((f2){pz.b1, pz.b1}, v1[yy][j],
+                                                  (f2){pz.b0, pz.b0} * v0[yy][j]));
+                }
+        };
+        const int back = top - pz.s0;
+        if (back == 2) blend(q0, q1, q2);
+        else if (back == 1) blend(q1, q2, q2);
+        else blend(q2, q2, q2);
+        store(za, oa);
+        if (has_zb) store(za + 1, ob);
     }
-    store(za, pa0, pa1, la);
-    if (!has_b) return;
-    // the second plane's sources: usually a1 and a1 + 1
-    f2 pb0[NF], pb1[NF];
-    if (b0 == a1) {
-#pragma unroll
-        for (int j = 0; j < NF; ++j) pb0[j] = pa1[j];
-    } else if (b0 == a0) {
-#pragma unroll
-        for (int j = 0; j < NF; ++j) pb0[j] = pa0[j];
-    } else {
-        plane(b0, pb0);
-    }
-    if (b1 == b0) {
-#pragma unroll
-        for (int j = 0; j < NF; ++j) pb1[j] = pb0[j];
-    } else if (b1 == a1) {
-#pragma unroll
-        for (int j = 0; j < NF; ++j) pb1[j] = pa1[j];
-    } else {
-        plane(b1, pb1);
-    }
-    store(za + 1, pb0, pb1, lb);
 }
 
 // ---- head: 1x1x1 conv (+ sigmoid), channels-last -> NCDHW float32 -----------
@@ -730,17 +788,18 @@ int launch_upsample2(int dtype, const void* src, void* dst, int n, int d, int h,
                      int c, int margin, hipStream_t stream) {
     if (margin < 0 || margin >= d || margin >= h || margin >= w) margin = 0;
     const int nv = n * (c * dtype_size(dtype) / 32);   // chunk planes = independent volumes
-    const long long plane = (long long)(h * 2 - 2 * margin) * (w * 2 - 2 * margin);   // voxels
-    const long long rowp = (long long)(w * 2 - 2 * margin);
-    const long long planes = (long long)nv * ((d * 2 - 2 * margin + 1) / 2);   // pairs of output planes
-    EXA_CHECK_ARG(planes <= 0x7fffffffLL && (plane + 255) / 256 <= 65535 && plane * rowp < 0xffffffffLL,
+    // items of one pair of output planes: (row pair, column, 16-byte group)
+    const long long items = (long long)((h * 2 - 2 * margin + 1) / 2) * (w * 2 - 2 * margin) * 2;
+    const int nzp = (d * 2 - 2 * margin + 1) / 2;                              // pairs of output planes
+    const long long planes = (long long)nv * ((nzp + kUpsZRun - 1) / kUpsZRun);  // runs of pairs
+    EXA_CHECK_ARG(planes <= 0x7fffffffLL && (items + 255) / 256 <= 65535 &&
+                      (long long)nv * d * h * w * 2 < 0x7fffffffLL,
                   "upsample: grid too large");
-    const unsigned row_magic = (unsigned)(0x100000000ULL / (unsigned long long)rowp) + 1u;
     auto scale = [](int in) { return in > 1 ? (float)(in - 1) / (float)(2 * in - 1) : 0.f; };
-    dim3 grid((unsigned)planes, (unsigned)((plane + 255) / 256));
+    dim3 grid((unsigned)planes, (unsigned)((items + 255) / 256));
     DISPATCH_T(dtype, (upsample2_kernel<T><<<grid, 256, 0, stream>>>(
                           static_cast<const uint4*>(src), static_cast<uint4*>(dst), d, h, w,
-                          row_magic, scale(d), scale(h), scale(w), margin)));
+                          scale(d), scale(h), scale(w), margin)));
     EXA_CHECK_HIP(hipGetLastError());
     return EXASPIM_OK;
 }
