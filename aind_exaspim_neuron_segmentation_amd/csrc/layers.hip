@@ -354,11 +354,41 @@ __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
+// (n, d, h, w) float32 -> (n, d+2, h+2, w+2) with a zero border, every voxel already split
+// into its two 16-bit parts, hi | lo << 16: a voxel is read by 27 taps of up to four
+// 32-cout slices, so the split (two conversions and a subtraction) is done here once per
+// voxel instead of once per use. One block per padded plane.
+template <typename T>
+__global__ __launch_bounds__(256) void pad_split_kernel(const float* __restrict__ x,
+                                                        unsigned* __restrict__ xp, int d, int h, int w) {
+    const int nb = blockIdx.x / (d + 2), pz = blockIdx.x - nb * (d + 2);
+    const int z = pz - 1;
+    const int pw = w + 2, plane = (h + 2) * pw;
+    unsigned* const dst = xp + (size_t)blockIdx.x * plane;
+    if ((unsigned)z >= (unsigned)d) {
+        for (int i = threadIdx.x; i < plane; i += blockDim.x) dst[i] = 0u;
+        return;
+    }
+    const float* const src = x + ((size_t)nb * d + z) * h * w;
+    for (int i = threadIdx.x; i < plane; i += blockDim.x) {
+        const int py = i / pw, px = i - py * pw;
+        const int y = py - 1, xx = px - 1;
+        unsigned v = 0u;
+        if ((unsigned)y < (unsigned)h && (unsigned)xx < (unsigned)w) {
+            const float f = src[y * w + xx];
+            const unsigned short hi = Half16<T>::bits(f);
+            const unsigned short lo = Half16<T>::bits(f - Half16<T>::value(hi));
+            v = (unsigned)hi | ((unsigned)lo << 16);
+        }
+        dst[i] = v;
+    }
+}
+
 // ROWS: the patch width is a multiple of 32, so a 32-voxel group is a piece of one row
 // and its position is decoded once per wave with scalar arithmetic.
 template <typename T, bool ROWS>
 __global__ __launch_bounds__(256) void conv_first16_kernel(
-    const float* __restrict__ xp, const float* __restrict__ w,
+    const unsigned* __restrict__ xp, const float* __restrict__ w,
     const float* __restrict__ bias, void* __restrict__ dst, int nvox, int d, int h, int wd,
     int c0p, float slope) {
     const int lane = threadIdx.x & 63;
@@ -397,27 +427,45 @@ __global__ __launch_bounds__(256) void conv_first16_kernel(
     __shared__ __attribute__((aligned(16))) char tr[4 * 32 * RECP];
     char* wl = tr + wave * (32 * RECP);
 
-    // a wave walks 32-voxel groups: the weight operands above are set up once
+    // a wave walks 32-voxel groups: the weight operands above are set up once, and the 16
+    // tap loads of the next group are in flight while the current one goes through the
+    // matrix pipe, LDS and the stores (a group alone is a chain of latencies)
     const int ngroups = (nvox + 31) / 32;
-    for (int grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gridDim.x * 4) {
-        int v, nb, sp, zz, yy, xx;
+    struct Pos {
+        const unsigned* base;   // padded address of tap (0,0,0) = voxel (zz-1, yy-1, xx-1)
+        int v, nb, sp;
+    };
+    auto locate = [&](int grp) {
+        Pos p;
+        int zz, yy, xx;
         if (ROWS) {
             const int g0 = __builtin_amdgcn_readfirstlane(grp) * 32;   // first voxel of the group
-            nb = g0 / dhw;
-            const int sp0 = g0 - nb * dhw;
+            p.nb = g0 / dhw;
+            const int sp0 = g0 - p.nb * dhw;
             zz = sp0 / hw;
             yy = (sp0 - zz * hw) / wd;
             xx = sp0 - zz * hw - yy * wd + r;
-            sp = sp0 + r;
-            v = g0 + r;
+            p.sp = sp0 + r;
+            p.v = g0 + r;
         } else {
-            v = grp * 32 + r;
-            const int vc = v < nvox ? v : nvox - 1;
-            nb = vc / dhw; sp = vc - nb * dhw;
-            zz = sp / hw; yy = (sp - zz * hw) / wd; xx = sp - zz * hw - yy * wd;
+            p.v = grp * 32 + r;
+            const int vc = p.v < nvox ? p.v : nvox - 1;
+            p.nb = vc / dhw; p.sp = vc - p.nb * dhw;
+            zz = p.sp / hw; yy = (p.sp - zz * hw) / wd; xx = p.sp - zz * hw - yy * wd;
         }
-        // padded address of tap (0,0,0) = voxel (zz-1, yy-1, xx-1)
-        const float* base = xp + ((size_t)nb * (d + 2) + zz) * phw + yy * pw + xx;
+        p.base = xp + ((size_t)p.nb * (d + 2) + zz) * phw + yy * pw + xx;
+        return p;
+    };
+    const int gstep = gridDim.x * 4;
+    int grp = blockIdx.x * 4 + wave;
+    if (grp >= ngroups) return;
+    auto load_taps = [&](const Pos& p, unsigned (*x)[8]) {   // hi | lo << 16 per tap (pad_split_kernel)
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[st][j] = p.base[rel[st][j]];
+    };
+    auto process = [&](const Pos& cur, int g, const unsigned (*x)[8]) {
         f32x16_ct acc;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -426,11 +474,12 @@ __global__ __launch_bounds__(256) void conv_first16_kernel(
         }
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-            float xv[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xv[j] = base[rel[st][j]];
+            // v_perm_b32: gather the low halves (hi parts) resp. the high halves (lo parts) of two taps
             uint4 xhi, xlo;
-            split8<T>(xv, xhi, xlo);
+            xhi.x = __builtin_amdgcn_perm(x[st][1], x[st][0], 0x05040100u); xlo.x = __builtin_amdgcn_perm(x[st][1], x[st][0], 0x07060302u);
+            xhi.y = __builtin_amdgcn_perm(x[st][3], x[st][2], 0x05040100u); xlo.y = __builtin_amdgcn_perm(x[st][3], x[st][2], 0x07060302u);
+            xhi.z = __builtin_amdgcn_perm(x[st][5], x[st][4], 0x05040100u); xlo.z = __builtin_amdgcn_perm(x[st][5], x[st][4], 0x07060302u);
+            xhi.w = __builtin_amdgcn_perm(x[st][7], x[st][6], 0x05040100u); xlo.w = __builtin_amdgcn_perm(x[st][7], x[st][6], 0x07060302u);
             mma_ct<T>(acc, whi[st], xhi);
             mma_ct<T>(acc, whi[st], xlo);
             mma_ct<T>(acc, wlo[st], xhi);
@@ -451,9 +500,9 @@ __global__ __launch_bounds__(256) void conv_first16_kernel(
         const int vv = lane >> 1, sub = lane & 1;
         int vo, nbo, spo;
         if (ROWS) {
-            vo = v - r + vv; nbo = nb; spo = sp - r + vv;
+            vo = cur.v - r + vv; nbo = cur.nb; spo = cur.sp - r + vv;
         } else {
-            vo = grp * 32 + vv;
+            vo = g * 32 + vv;
             const int voc = vo < nvox ? vo : nvox - 1;
             nbo = voc / dhw; spo = voc - nbo * dhw;
         }
@@ -467,6 +516,20 @@ __global__ __launch_bounds__(256) void conv_first16_kernel(
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    };
+    // two tap buffers in turn: the loads of group i + 1 are issued before group i is processed
+    unsigned xa[2][8], xb[2][8];
+    Pos pa = locate(grp), pb = pa;
+    load_taps(pa, xa);
+    for (;;) {
+        if (grp + gstep < ngroups) { pb = locate(grp + gstep); load_taps(pb, xb); }
+        process(pa, grp, xa);
+        grp += gstep;
+        if (grp >= ngroups) break;
+        if (grp + gstep < ngroups) { pa = locate(grp + gstep); load_taps(pa, xa); }
+        process(pb, grp, xb);
+        grp += gstep;
+        if (grp >= ngroups) break;
     }
 }
 
@@ -728,7 +791,14 @@ int launch_conv_first(int dtype, const float* x, float* xpad, const float* w, co
     const size_t blocks = (nvox + 4 * MT * 32 - 1) / (4 * MT * 32);
     EXA_CHECK_ARG(nvox > 0 && nvox < 0x7fffffffULL && c0p % 32 == 0, "conv_first: bad size");
     EXA_CHECK_ARG((long long)n * (d + 2) <= 65535 && h + 2 <= 65535, "conv_first: grid too large");
-    pad_input_kernel<<<(unsigned)((long long)n * (d + 2)), 256, 0, stream>>>(x, xpad, d, h, wd);
+    const unsigned pad_blocks = (unsigned)((long long)n * (d + 2));
+    unsigned* const xsplit = reinterpret_cast<unsigned*>(xpad);   // 16-bit modes: hi | lo << 16 per voxel
+    switch (dtype) {
+        case EXASPIM_DT_F32: pad_input_kernel<<<pad_blocks, 256, 0, stream>>>(x, xpad, d, h, wd); break;
+        case EXASPIM_DT_BF16: pad_split_kernel<BF16T><<<pad_blocks, 256, 0, stream>>>(x, xsplit, d, h, wd); break;
+        case EXASPIM_DT_F16: pad_split_kernel<F16T><<<pad_blocks, 256, 0, stream>>>(x, xsplit, d, h, wd); break;
+        default: set_error("unknown dtype %d", dtype); return EXASPIM_E_INVALID;
+    }
     EXA_CHECK_HIP(hipGetLastError());
     dim3 grid((unsigned)blocks, c0p / 32);
     // the 16-bit kernel's waves walk the 32-voxel groups: 8 workgroups per CU are plenty
@@ -740,15 +810,15 @@ int launch_conv_first(int dtype, const float* x, float* xpad, const float* w, co
             break;
         case EXASPIM_DT_BF16:
             if (wd % 32 == 0)
-                conv_first16_kernel<BF16T, true><<<grid16, 256, 0, stream>>>(xpad, w, bias, dst, (int)nvox, d, h, wd, c0p, slope);
+                conv_first16_kernel<BF16T, true><<<grid16, 256, 0, stream>>>(xsplit, w, bias, dst, (int)nvox, d, h, wd, c0p, slope);
             else
-                conv_first16_kernel<BF16T, false><<<grid16, 256, 0, stream>>>(xpad, w, bias, dst, (int)nvox, d, h, wd, c0p, slope);
+                conv_first16_kernel<BF16T, false><<<grid16, 256, 0, stream>>>(xsplit, w, bias, dst, (int)nvox, d, h, wd, c0p, slope);
             break;
         case EXASPIM_DT_F16:
             if (wd % 32 == 0)
-                conv_first16_kernel<F16T, true><<<grid16, 256, 0, stream>>>(xpad, w, bias, dst, (int)nvox, d, h, wd, c0p, slope);
+                conv_first16_kernel<F16T, true><<<grid16, 256, 0, stream>>>(xsplit, w, bias, dst, (int)nvox, d, h, wd, c0p, slope);
             else
-                conv_first16_kernel<F16T, false><<<grid16, 256, 0, stream>>>(xpad, w, bias, dst, (int)nvox, d, h, wd, c0p, slope);
+                conv_first16_kernel<F16T, false><<<grid16, 256, 0, stream>>>(xsplit, w, bias, dst, (int)nvox, d, h, wd, c0p, slope);
             break;
         default: set_error("unknown dtype %d", dtype); return EXASPIM_E_INVALID;
     }
