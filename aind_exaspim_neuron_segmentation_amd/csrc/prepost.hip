@@ -49,21 +49,21 @@ template <>
 __device__ __forceinline__ int bin_of<EXASPIM_VOX_U8>(const void* vol, size_t i, double clip,
                                                       int has_clip, int, unsigned) {
     int v = static_cast<const uint8_t*>(vol)[i];
-    if (has_clip && (double)v > clip) v = (int)clip;
+    if (has_clip && (double)v > clip) v = (int)ceil(clip);   // a fractional clip gets the bin above its floor
     return v;
 }
 template <>
 __device__ __forceinline__ int bin_of<EXASPIM_VOX_U16>(const void* vol, size_t i, double clip,
                                                        int has_clip, int, unsigned) {
     int v = static_cast<const uint16_t*>(vol)[i];
-    if (has_clip && (double)v > clip) v = (int)clip;
+    if (has_clip && (double)v > clip) v = (int)ceil(clip);   // a fractional clip gets the bin above its floor
     return v;
 }
 template <>
 __device__ __forceinline__ int bin_of<EXASPIM_VOX_I16>(const void* vol, size_t i, double clip,
                                                        int has_clip, int, unsigned) {
     int v = static_cast<const int16_t*>(vol)[i];
-    if (has_clip && (double)v > clip) v = (int)clip;
+    if (has_clip && (double)v > clip) v = (int)ceil(clip);   // a fractional clip gets the bin above its floor
     return v + 32768;
 }
 template <>

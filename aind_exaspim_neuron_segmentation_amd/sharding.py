@@ -345,7 +345,8 @@ def predict_shard(volume, model, plan, shard, n_channels=3, batch_size=16,
             shard.input_origin,
         )
         core = inference.DeviceVolume(
-            volume.tensor[core_sl].contiguous(), volume.np_dtype, shard.core_origin, plan.shape
+            volume.tensor[core_sl].contiguous(), volume.np_dtype, shard.core_origin, plan.shape,
+            storage_dtype=volume.storage_dtype,
         )
 
         def reduce_fn(hist):

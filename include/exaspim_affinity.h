@@ -145,7 +145,7 @@ int exaspim_unet_forward_trimmed(exaspim_unet* h, const float* x_dev, float* out
 /* Measurement hooks (bench.py's roofline leg). timing_begin arms HIP-event
  * timing, on the launch stream, of the MFMA convolutions whose bit is set in
  * conv_mask (bit i = i-th 3x3x3 conv after inc.0 in state_dict order: inc.3,
- * down1.0, down1.3, ... up4.0 = bit 15, up4.3 = bit 16); at most 4096 launches
+ * down1.0, down1.3, ... up4.0 = bit 15, up4.3 = bit 16); at most 16384 launches
  * are recorded. timing_read waits for the recorded events and returns, per
  * conv, the summed milliseconds and the number of launches, then disarms. */
 int exaspim_unet_timing_begin(exaspim_unet* h, uint32_t conv_mask);
@@ -157,7 +157,9 @@ int exaspim_unet_timing_read(exaspim_unet* h, double ms_sum[17], int32_t count[1
 
 /* Adds the 65536-bin histogram of min(voxel, clip) (clip applied iff
  * has_clip) over "n" voxels into hist_dev (uint64[65536], caller-zeroed).
- * 8/16-bit integer voxels are binned by value (I16: value + 32768). F32
+ * 8/16-bit integer voxels are binned by value (I16: value + 32768); with a
+ * fractional clip (np.minimum promotes the image to float64) every voxel above
+ * it lands in bin ceil(clip), which then stands for the clip value itself. F32
  * voxels are binned by an order-preserving 32-bit key: pass 0 bins the key's
  * high 16 bits; pass 1 bins the low 16 bits of keys whose high half equals
  * "prefix". Order statistics, and from them numpy's linear-interpolated

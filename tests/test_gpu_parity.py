@@ -579,14 +579,55 @@ def test_predict_voxel_dtypes_vs_oracle(dev, oracle, name, clip):
     np.testing.assert_array_equal(got == 0, want == 0)
 
 
-def test_predict_rejects_dtype_promoting_clip(dev):
+@pytest.mark.parametrize("name,clip", [("i32", 1000), ("u32", 700), ("i64", 1000), ("u64", 900), ("f64", 123.5),
+                                       ("i8", 100), ("u16_fractional_clip", 1000.5), ("u8_fractional_clip", 200.25),
+                                       ("i32_fractional_clip", 800.5)])
+def test_predict_takes_the_dtypes_the_reference_takes(dev, oracle, name, clip):
+    """inference.py:79-80 runs on any numeric array: wider integers and float64 travel to
+    the device as float32 (exactly representable values), int8 as int16, and a clip that
+    makes np.minimum promote an integer image to float64 is evaluated the same way
+    (voxels above it take the clip's own, fractional, value)."""
+    from aind_exaspim_neuron_segmentation_amd import inference
+
+    base = _volumes()["u16"]  # (40, 48, 56), values 0..1999
+    vol = {
+        "i32": base.astype(np.int32) - 300,
+        "u32": base.astype(np.uint32) * 3,
+        "i64": base.astype(np.int64) * 7 - 2000,
+        "u64": base.astype(np.uint64),
+        "f64": base.astype(np.float64) * 0.25 - 11.5,
+        "i8": (base % 251).astype(np.int16).astype(np.int8),
+        "u16_fractional_clip": base,
+        "u8_fractional_clip": (base % 251).astype(np.uint8),
+        "i32_fractional_clip": base.astype(np.int32) - 300,
+    }[name]
+    model, sd = make_model(dev)
+    kw = dict(batch_size=4, patch_shape=(32, 32, 32), overlap=(16, 8, 8), trim=4,
+              brightness_clip=clip, normalization_percentiles=(2, 98.5))
+    want = oracle.predict(vol, oracle.OracleModel(sd), **kw)
+    got = inference.predict(vol, model, verbose=False, **kw)
+    err = np.abs(got - want).max()
+    print(f"predict {name}: max|diff| = {err:.3e}")
+    assert err < 1e-5
+    np.testing.assert_array_equal(got == 0, want == 0)
+    # percentiles are numpy's, bit for bit
+    dv = inference.DeviceVolume.from_array(vol, dev)
+    mn, mx = inference.volume_percentiles(dv, clip, (2, 98.5))
+    ref = np.percentile(np.minimum(vol, clip), (2, 98.5))
+    assert (mn, mx) == (ref[0], ref[1])
+
+
+def test_predict_rejects_what_float32_cannot_carry(dev):
     from aind_exaspim_neuron_segmentation_amd import inference
 
     model, _ = make_model(dev)
     vol = _volumes()["u16"]
-    with pytest.raises(NotImplementedError, match="promotes"):
-        inference.predict(vol, model, brightness_clip=1000.5, patch_shape=(32, 32, 32),
-                          overlap=(8, 8, 8), trim=4, verbose=False)
+    kw = dict(patch_shape=(32, 32, 32), overlap=(8, 8, 8), trim=4, verbose=False)
+    with pytest.raises(TypeError, match="not exactly representable"):
+        inference.predict(vol.astype(np.int64) + ((1 << 40) + 1), model, **kw)
+    with pytest.raises(TypeError, match="not exactly representable"):
+        inference.predict(vol.astype(np.float64) + 1e-9, model, **kw)
     with pytest.raises(TypeError, match="not supported"):
-        inference.predict(vol.astype(np.int64), model, patch_shape=(32, 32, 32),
-                          overlap=(8, 8, 8), trim=4, verbose=False)
+        inference.predict(vol.astype(np.complex64), model, **kw)
+    with pytest.raises(OverflowError):          # numpy's own refusal (inference.py:79)
+        inference.predict((vol % 251).astype(np.uint8), model, brightness_clip=1000, **kw)

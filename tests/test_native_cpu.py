@@ -272,3 +272,39 @@ def test_validation_tiling_matches_reference_golden(golden):
         kept = [c for c in centers if img_util.is_contained(c, vol, buffer=64)]
         np.testing.assert_array_equal(np.array(kept, dtype=np.int64).reshape(-1, 3),
                                       g[f"case{i}_centers_kept"])
+
+
+def test_dtype_rules_and_fractional_clip_percentiles_on_the_host():
+    """Host logic behind the voxel dtypes predict() takes: storage dtype per image dtype,
+    numpy's np.minimum promotion, and np.percentile rebuilt from a 65536-bin histogram in
+    which the voxels above a fractional clip sit in bin ceil(clip) (csrc/prepost.hip)."""
+    import numpy as np
+    from aind_exaspim_neuron_segmentation_amd import inference as inf
+
+    for dt, want in ((np.uint8, np.uint8), (np.int8, np.int16), (np.uint16, np.uint16), (np.int16, np.int16),
+                     (np.float32, np.float32), (np.int32, np.float32), (np.uint32, np.float32),
+                     (np.int64, np.float32), (np.uint64, np.float32), (np.float64, np.float32)):
+        storage, convert = inf._device_voxel_dtype(dt)
+        assert storage == np.dtype(want)
+        block = (np.arange(24).reshape(2, 3, 4) % 7).astype(dt)
+        np.testing.assert_array_equal(convert(block).astype(np.float64), block.astype(np.float64))
+    with pytest.raises(TypeError):
+        inf._device_voxel_dtype(np.int64)[1](np.array([[[(1 << 40) + 1]]], dtype=np.int64))
+    assert inf._device_voxel_dtype(np.complex64)[0] not in inf._VOX_CODES
+
+    assert inf._effective_clip(np.uint16, 1000) == (np.uint16(1000), np.dtype(np.uint16))
+    assert inf._effective_clip(np.uint16, None) == (None, np.dtype(np.uint16))
+    assert inf._effective_clip(np.uint16, 1000.5) == (np.float64(1000.5), np.dtype(np.float64))
+    assert inf._effective_clip(np.float32, 123.5) == (np.float32(123.5), np.dtype(np.float32))
+    with pytest.raises(OverflowError):
+        inf._effective_clip(np.uint8, 1000)
+    with pytest.raises(NotImplementedError):      # int32 travels as float32; 0.1 is not a float32 number
+        inf._effective_clip(np.int32, 0.1)
+
+    vol = synthetic.synth_volume((24, 20, 28), seed=5)
+    for clip in (1000.5, 37.25, 5000.75):
+        bins = np.where(vol.astype(np.float64) > clip, int(np.ceil(clip)), vol).astype(np.int64)
+        hist = np.bincount(bins.ravel(), minlength=65536)
+        c, vdt = inf._effective_clip(vol.dtype, clip)
+        got = inf._percentiles_from_histograms(lambda *a: hist, vol.dtype, (1, 99.9), vdt, c)
+        np.testing.assert_array_equal(np.array(got), np.percentile(np.minimum(vol, clip), (1, 99.9)))
