@@ -42,6 +42,28 @@ const char* get_error();
 constexpr int kChannelPad = 32;
 constexpr int kNumMfmaConvs = 17;  // every 3x3x3 conv except inc.0 (Cin = 1)
 
+// Paired-tap fragments of the z-column kernel on v_mfma_f32_16x16x32 (conv3d.hip,
+// conv3x3x3_zpair): per 16-channel chunk 32 A fragments [16 couts x (2 taps x 16 channels)].
+// Fragments 0..23 = pair * 6 + dz * 2 + t for the in-plane tap pairs (0,3) (1,4) (2,5) (6,7)
+// (g = dy * 3 + dx; both taps in plane dz); 24..31 = 24 + kind * 2 + t for tap g = 8 chained
+// over two consecutive input planes: kind 0 = [dz 0; dz 1], 1 = [dz 2; -], 2 = [-; dz 0],
+// 3 = [dz 1; dz 2]. t = 16-cout half of the 32-cout slice.
+constexpr int kPairedFrags = 32;
+// (tap of the first, tap of the second 16-channel half; -1 = zero weights) of a fragment
+inline void paired_frag_taps(int frag, int* tap0, int* tap1) {
+    static const int pair_g[4][2] = {{0, 3}, {1, 4}, {2, 5}, {6, 7}};
+    if (frag < 24) {
+        const int pair = frag / 6, dz = (frag % 6) / 2;
+        *tap0 = dz * 9 + pair_g[pair][0];
+        *tap1 = dz * 9 + pair_g[pair][1];
+    } else {
+        static const int kind_dz[4][2] = {{0, 1}, {2, -1}, {-1, 0}, {1, 2}};
+        const int kind = (frag - 24) / 2;
+        *tap0 = kind_dz[kind][0] < 0 ? -1 : kind_dz[kind][0] * 9 + 8;
+        *tap1 = kind_dz[kind][1] < 0 ? -1 : kind_dz[kind][1] * 9 + 8;
+    }
+}
+
 inline int pad_channels(int c) { return (c + kChannelPad - 1) / kChannelPad * kChannelPad; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int dtype_size(int dtype) { return dtype == EXASPIM_DT_F32 ? 4 : 2; }
@@ -51,6 +73,8 @@ struct ConvLayer {
     int ca = 0, cb = 0;            // padded
     int cout_real = 0, cout = 0;   // real / padded output channels
     size_t w_off = 0;              // packed weights (compute dtype), bytes
+    size_t w2_off = 0;             // the same weights in paired-tap fragment order (16-bit modes,
+                                   // 32-cout-slice layers: conv3x3x3_zpair), 0 if not packed
     size_t b_off = 0;              // folded bias, float[cout], bytes
     size_t p_off = 0;              // offset of this conv's block in params
 };
@@ -94,6 +118,7 @@ struct ConvArgs {
     const void* src_b;
     int ca, cb;          // padded channel counts of the two sources (cb may be 0)
     const void* weights; // packed fragments
+    const void* weights_paired = nullptr;   // paired-tap fragments (ConvLayer::w2_off), or null
     const float* bias;
     void* dst;
     int cout;            // padded

@@ -37,6 +37,9 @@
 //                   from L2 through a register ring.
 // Both prefetch the next chunk global -> VGPR under the current chunk's MFMAs.
 
+#include <cstdlib>
+#include <type_traits>
+
 #include "common.h"
 
 namespace exaspim {
@@ -45,6 +48,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 struct F32Tag { static constexpr int kG = 4; };
 struct BF16Tag { static constexpr int kG = 8; };
@@ -69,6 +74,24 @@ template <>
 __device__ __forceinline__ void mma<F16Tag>(f32x16& acc, const uint4& wf, const uint4& xf) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf),
                                                  __builtin_bit_cast(f16x8, xf), acc, 0, 0, 0);
+}
+
+// In-place form for the z-column kernel: destination tied to the addend ("+v"). Left to the
+// register allocator, many MFMAs of the unrolled tap loop got a destination different from
+// their addend (both accumulator copies live for a while) and the kernel, already at its
+// 256 registers, spilled; a spilled value comes back through a scratch load whose wait also
+// waits for every prefetch load and store still in flight.
+template <typename Tag>
+__device__ __forceinline__ void mma_inplace(f32x16& acc, const uint4& wf, const uint4& xf) { mma<Tag>(acc, wf, xf); }
+template <>
+__device__ __forceinline__ void mma_inplace<BF16Tag>(f32x16& acc, const uint4& wf, const uint4& xf) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0"
+                 : "+v"(acc) : "v"(__builtin_bit_cast(u32x4_t, wf)), "v"(__builtin_bit_cast(u32x4_t, xf)));
+}
+template <>
+__device__ __forceinline__ void mma_inplace<F16Tag>(f32x16& acc, const uint4& wf, const uint4& xf) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0"
+                 : "+v"(acc) : "v"(__builtin_bit_cast(u32x4_t, wf)), "v"(__builtin_bit_cast(u32x4_t, xf)));
 }
 
 // LeakyReLU with 0 <= slope <= 1 is max(v, slope * v): one multiply and one bare v_max_f32
@@ -533,9 +556,14 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
     };
     auto tile_at = [&](int id) {
         Tile t;
-        t.x0 = a.org[2] + (id % tiles_x) * TX; id /= tiles_x;
-        t.y0 = a.org[1] + (id % tiles_y) * TY; id /= tiles_y;
-        t.z0 = a.org[0] + (id % tiles_z) * TZ; id /= tiles_z;
+        // (x fastest. Measured alternative, z fastest -- whole z-columns resident in an XCD's L2
+        // together so that neighbours share their two halo planes: HBM reads 1363 -> 1429 MB per
+        // inc.3 launch, 1 % slower.) The divisions run on the vector ALU; readfirstlane puts the
+        // wave-uniform results back into scalar registers.
+        t.x0 = __builtin_amdgcn_readfirstlane(a.org[2] + (id % tiles_x) * TX); id /= tiles_x;
+        t.y0 = __builtin_amdgcn_readfirstlane(a.org[1] + (id % tiles_y) * TY); id /= tiles_y;
+        t.z0 = __builtin_amdgcn_readfirstlane(a.org[0] + (id % tiles_z) * TZ); id /= tiles_z;
+        id = __builtin_amdgcn_readfirstlane(id);
         t.nb = id;
         return t;
     };
@@ -723,7 +751,7 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
 #pragma unroll
                 for (int dz = 0; dz < 3; ++dz) {
                     const int z = zin - dz;
-                    if (z >= 0 && z < TZ) mma<Tag>(acc[z], wb[dz], xr[s % R]);
+                    if (z >= 0 && z < TZ) mma_inplace<Tag>(acc[z], wb[dz], xr[s % R]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -877,6 +905,473 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
     }
 }
 
+// ---- conv3x3x3_zpair: the z-column kernel on v_mfma_f32_16x16x32 (16-bit modes) ----------
+// Under the package power cap the 16x16x32 shape sustains ~15 % more FLOP/s than 32x32x16
+// at equal operand traffic (tools/mfma_shape.hip). Its K is 32: with
+// 16-channel chunks in the LDS image that is two taps per instruction. Same tiles, same
+// image, same staging as conv3x3x3_zpipe; what changes is how the 27 taps are walked:
+//   * in-plane taps in pairs (0,3) (1,4) (2,5) (6,7) (g = dy * 3 + dx): the B operand of a
+//     (pair, input plane, 16-voxel row) is ONE ds_read_b128 -- lanes 0-31 read the first
+//     tap's 16 channels, lanes 32-63 the second tap's, HXP or 1 slot further -- and feeds
+//     the three dz taps x two 16-cout halves = 6 MFMAs (96 cycles), the same reads per FLOP
+//     as before;
+//   * tap 8 is chained over two consecutive input planes (lanes 32-63 read PLANE slots
+//     further): [X(p); X(p+1)] serves out planes p (weights [dz0; dz1]) and p+1 ([-; dz0]) in
+//     a first pass over p = 0, 2, .., and p-2 ([dz2; -]) and p-1 ([dz1; dz2]) in a second
+//     one: 14 instruction pairs per output plane where 13.5 would be ideal (3.7 %).
+// A wave owns two rows of 16 voxels x TZ planes x 2 cout halves = the same 16 * TZ
+// accumulator registers. Weight fragments come in the paired order plan.cpp packs
+// (common.h, kPairedFrags = 32 per chunk, 32 KB in LDS).
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N) -- the step index of
+// the tap loop must be a constant in every register-array subscript
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <typename Tag>
+__device__ __forceinline__ void mma16(f32x4& acc, const uint4& wf, const uint4& xf);
+// The accumulators are pinned to the accumulation registers ("+a") and updated in place:
+// left to itself hipcc kept them in VGPRs, gave many MFMAs a destination different from
+// their addend (40 accumulator quads live instead of 24) and spilled.
+template <>
+__device__ __forceinline__ void mma16<BF16Tag>(f32x4& acc, const uint4& wf, const uint4& xf) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+                 : "+v"(acc) : "v"(__builtin_bit_cast(u32x4, wf)), "v"(__builtin_bit_cast(u32x4, xf)));
+}
+template <>
+__device__ __forceinline__ void mma16<F16Tag>(f32x4& acc, const uint4& wf, const uint4& xf) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0"
+                 : "+v"(acc) : "v"(__builtin_bit_cast(u32x4, wf)), "v"(__builtin_bit_cast(u32x4, xf)));
+}
+
+template <typename Tag, int TZ, int TY, int MINW, int D, int HEAD = 0, bool POOL = false>
+__global__ __launch_bounds__(TY * 16 * 2, MINW) void conv3x3x3_zpair(
+    ConvArgs a, int tiles_z, int tiles_y, int tiles_x) {
+    constexpr int TX = 16;
+    constexpr int KC = 16, ES = 2;
+    constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+    constexpr int HXP = HX;                // row stride (slots)
+    constexpr int PLANE = HY * HXP;        // slots per halo plane
+    constexpr int HVP = HZ * PLANE;        // slots per channel group
+    // stride between the two channel-group planes: a multiple of 16 slots, so the lane
+    // quarters of one ds_read_b128 group (16 voxels of group 0 next to 16 of group 1) fall
+    // on complementary banks
+    constexpr int GS = (HVP + 15) / 16 * 16;
+    constexpr int NWAVES = TY / 2;
+    constexpr int NTHREADS = NWAVES * 64;
+    constexpr int NPAIR = 2 * HY * HX;     // (column, group) pairs of the halo block
+    constexpr int REM = NPAIR > NTHREADS ? NPAIR - NTHREADS : 0;
+    constexpr int SEC = (REM * HZ + NTHREADS - 1) / NTHREADS;
+    constexpr int NITEMS = HZ + SEC;       // halo pieces per thread
+    constexpr int RECB = 32 * ES;
+    constexpr int RECP = RECB + 16;        // padded LDS stride of the output transposition
+    constexpr int EPI_UNITS = NWAVES * 32 * RECP / 16;
+    constexpr int WUNITS = kPairedFrags * 64;   // the chunk's weight fragments in LDS
+    constexpr int WITEMS = (WUNITS + NTHREADS - 1) / NTHREADS;
+    constexpr int XUNITS = 2 * GS > EPI_UNITS ? 2 * GS : EPI_UNITS;
+    constexpr int LDS_UNITS = XUNITS + WUNITS;
+    constexpr int NSAME = 4 * HZ * 2;      // steps of the four in-plane pairs: (pair, plane, row)
+    constexpr int NS = NSAME + 2 * TZ;     // + the two passes over the chained tap
+    constexpr int R = D + 1;               // operand ring
+    static_assert(TZ % 2 == 0 && TY % 2 == 0 && NPAIR <= 2 * NTHREADS, "tile shape");
+    static_assert(NITEMS + WITEMS <= NS, "one staged piece per step");
+    static_assert(WUNITS % NTHREADS == 0, "weight fragments split evenly over the threads");
+
+    __shared__ __attribute__((aligned(16))) uint4 lds[LDS_UNITS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int quarter = lane >> 4;         // K slice of the MFMA operands: (tap slot, channel group)
+    const int lx = lane & 15;              // voxel column inside the 16-wide row
+
+    const int total = tiles_z * tiles_y * tiles_x * a.n;
+    int t_first, t_count, t_step;
+    {
+        const int q = total >> 3, rem = total & 7;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        t_first = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
+        t_count = q + (xcd < rem ? 1 : 0) - slot;        // tiles left from t_first on
+        t_step = (gridDim.x + 7 - xcd) >> 3;             // workgroups on this XCD
+    }
+    if (t_count <= 0) return;
+    const int ntiles = a.cout >> 5;
+    const int ntile0 = blockIdx.y;
+
+    struct Tile {
+        int z0, y0, x0, nb;
+    };
+    auto tile_at = [&](int id) {
+        // (the divisions run on the vector ALU; readfirstlane puts the wave-uniform results back
+        // into scalar registers, where every later use -- selects, scalar load offsets -- wants them)
+        Tile t;
+        t.x0 = __builtin_amdgcn_readfirstlane(a.org[2] + (id % tiles_x) * TX); id /= tiles_x;
+        t.y0 = __builtin_amdgcn_readfirstlane(a.org[1] + (id % tiles_y) * TY); id /= tiles_y;
+        t.z0 = __builtin_amdgcn_readfirstlane(a.org[0] + (id % tiles_z) * TZ); id /= tiles_z;
+        t.nb = __builtin_amdgcn_readfirstlane(id);
+        return t;
+    };
+
+    // LDS slot of this lane's voxel of row 0 of the wave, tap (0,0), plane 0, in its channel
+    // group; lanes 32-63 (second tap of a pair) sit one row, one column or one plane further
+    const int cbase = (quarter & 1) * GS + (wave * 2) * HXP + lx;
+    const int colH = cbase + (quarter >> 1) * HXP;
+    const int col1 = cbase + (quarter >> 1);
+    const int colP = cbase + (quarter >> 1) * PLANE;
+
+    // ---- staging map (as in conv3x3x3_zpipe) ------------------------------------------
+    // primary: thread t < NPAIR moves pair t = (column t / 2, group t & 1), all HZ planes;
+    // secondary: the REM pairs beyond NTHREADS, piece q = t + k * NTHREADS is plane q / REM of
+    // pair NTHREADS + q % REM. Nothing of this map is kept in registers: slots and global
+    // offsets are derived from the thread index where they are needed (a few multiply-shifts
+    // per piece). This kernel has no register to spare, and a spilled value comes back through
+    // a scratch load whose wait also waits for every prefetch load and store still in flight.
+    const int plane_vox = a.h * a.w;
+    const size_t patch_vox = (size_t)a.d * plane_vox;
+    // (the asm keeps the decoding next to its use: hoisted out of the loops it would live in registers)
+    auto my_tid = [&]() { int v = tid; asm volatile("" : "+v"(v)); return v; };
+    struct Item { int hz, hy, hx, kg; bool valid; };
+    auto primary = [&]() {
+        const int t = my_tid();
+        return Item{0, (t >> 1) / HX, (t >> 1) % HX, t & 1, t < NPAIR};
+    };
+    auto secondary = [&](int k) {
+        const int q = my_tid() + k * NTHREADS;
+        const int pr = NTHREADS + q % (REM > 0 ? REM : 1), c = pr >> 1;
+        return Item{q / (REM > 0 ? REM : 1), c / HX, c % HX, pr & 1, q < REM * HZ};
+    };
+    auto slot_of = [&](const Item& it) { return it.kg * GS + it.hz * PLANE + it.hy * HXP + it.hx; };
+    // byte offset of an item inside a chunk plane of the tile at (z0, y0, x0); primary items get
+    // their plane through the scalar offset (z = 0 here)
+    auto voff_of = [&](const Item& it, int z0, int y0, int x0, bool with_z) {
+        const int gz = z0 + it.hz - 1, gy = y0 + it.hy - 1, gx = x0 + it.hx - 1;
+        const bool in = it.valid && (!with_z || (unsigned)gz < (unsigned)a.d) &&
+                        (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
+        return in ? (unsigned)(((with_z ? gz : 0) * a.h + gy) * a.w + gx) * 32u + it.kg * 16u : kOutOfRange;
+    };
+
+    __shared__ __attribute__((aligned(16))) float bias_s[32];
+    if (tid < 32) bias_s[tid] = a.bias[ntile0 * 32 + tid];
+    __shared__ __attribute__((aligned(16))) float head_s[HEAD > 0 ? HEAD * 32 + 4 : 4];
+    if (HEAD > 0) {
+        if (tid < HEAD * 32) head_s[tid] = a.head_w[tid];
+        if (tid < HEAD) head_s[HEAD * 32 + tid] = a.head_b[tid];
+    }
+
+    const int nchunks = (a.ca + a.cb) / KC;
+    uint4 stg[NITEMS + WITEMS];  // halo pieces, then weight fragments
+    uint4* const wlds = lds + XUNITS;
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        make_rsrc(a.weights_paired, (size_t)nchunks * kPairedFrags * ntiles * 1024);
+
+    struct ChunkSrc {
+        __amdgpu_buffer_rsrc_t rsrc;
+        unsigned cbase;
+    };
+    auto chunk_src = [&](int c, int nb) {
+        const char* src;
+        int cs, ch0;
+        if (c * KC < a.ca) {
+            src = static_cast<const char*>(a.src_a); cs = a.ca; ch0 = c * KC;
+        } else {
+            src = static_cast<const char*>(a.src_b); cs = a.cb; ch0 = c * KC - a.ca;
+        }
+        const size_t patchb = patch_vox * cs * ES;
+        return ChunkSrc{make_rsrc(src + (size_t)nb * patchb, patchb),
+                        (unsigned)(ch0 / KC) * (unsigned)patch_vox * 32u};
+    };
+    // piece i of chunk c of the tile at (z0, y0, x0): global -> stg[i]; p_voff = voff_of(primary)
+    auto load_piece = [&](const ChunkSrc& cs, int c, int z0, int y0, int x0, unsigned p_voff, int i) {
+        if (i < NITEMS) {
+            if (i < HZ) {
+                const int gz = z0 + i - 1;  // wave-uniform
+                stg[i] = (unsigned)gz < (unsigned)a.d
+                             ? buf_load16(cs.rsrc, p_voff, cs.cbase + (unsigned)gz * plane_vox * 32u)
+                             : make_uint4(0, 0, 0, 0);
+            } else {
+                stg[i] = buf_load16(cs.rsrc, voff_of(secondary(i - HZ), z0, y0, x0, true), cs.cbase);
+            }
+        } else {
+            const int it = i - NITEMS;   // fragments it * NWAVES + wave
+            stg[i] = buf_load16(wrsrc, (unsigned)lane * 16u,
+                                ((c * kPairedFrags + it * NWAVES + wave) * ntiles + ntile0) * 1024);
+        }
+    };
+    auto stage_store = [&]() {
+        {
+            const Item it = primary();
+            if (it.valid) {
+                const int p_slot = slot_of(it);
+#pragma unroll
+                for (int hz = 0; hz < HZ; ++hz) lds[p_slot + hz * PLANE] = stg[hz];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < SEC; ++k) {
+            const Item it = secondary(k);
+            if (it.valid) lds[slot_of(it)] = stg[HZ + k];
+        }
+#pragma unroll
+        for (int it = 0; it < WITEMS; ++it) wlds[tid + it * NTHREADS] = stg[NITEMS + it];
+    };
+
+    int tile_id = t_first;
+    Tile cur = tile_at(tile_id);
+    {
+        const ChunkSrc cs0 = chunk_src(0, cur.nb);
+        const unsigned pv = voff_of(primary(), cur.z0, cur.y0, cur.x0, false);
+#pragma unroll
+        for (int i = 0; i < NITEMS + WITEMS; ++i) load_piece(cs0, 0, cur.z0, cur.y0, cur.x0, pv, i);
+    }
+    stage_store();
+
+    // ---- step tables (all compile-time after unrolling) ------------------------------
+    // LDS slot offset (beyond colH / col1 / colP) of the B operand of step s
+    constexpr auto x_off = [](int s) constexpr {
+        if (s < NSAME) {
+            const int pair = s / (2 * HZ), p = (s % (2 * HZ)) / 2, v = s % 2;
+            const int dy0 = pair < 3 ? 0 : 2, dx0 = pair < 3 ? pair : 0;
+            return p * PLANE + (v + dy0) * HXP + dx0;
+        }
+        const int c = s - NSAME;
+        const int p = c < TZ ? (c / 2) * 2 : ((c - TZ) / 2) * 2 + 2, v = c % 2;
+        return p * PLANE + (v + 2) * HXP + 2;
+    };
+    // which of colH / col1 / colP the step reads through
+    constexpr auto x_col = [](int s) constexpr { return s >= NSAME ? 2 : s / (2 * HZ) < 3 ? 0 : 1; };
+
+    for (;;) {
+        __syncthreads();   // this tile's first chunk (and, the first time, the bias) is in LDS
+        // accumulators: register k of acc[z][v][t] is channel 16 t + 4 quarter + k of voxel (row v, lx)
+        f32x4 acc[TZ][2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float4 b = *reinterpret_cast<const float4*>(bias_s + 16 * t + 4 * quarter);
+#pragma unroll
+            for (int z = 0; z < TZ; ++z)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    acc[z][v][t][0] = b.x; acc[z][v][t][1] = b.y;
+                    acc[z][v][t][2] = b.z; acc[z][v][t][3] = b.w;
+                }
+        }
+
+        t_count -= t_step;
+        const bool has_next = t_count > 0;
+        Tile nxt = cur;
+        for (int c = 0; c < nchunks; ++c) {
+            const bool more = c + 1 < nchunks;
+            const bool pre = more || has_next;
+            if (!more && has_next) nxt = tile_at(tile_id + t_step);
+            // the prefetch target: the next chunk of this tile, or the first chunk of the next tile
+            Tile tgt;
+            tgt.z0 = more ? cur.z0 : nxt.z0; tgt.y0 = more ? cur.y0 : nxt.y0;
+            tgt.x0 = more ? cur.x0 : nxt.x0; tgt.nb = more ? cur.nb : nxt.nb;
+            const ChunkSrc csn = chunk_src(more ? c + 1 : 0, tgt.nb);
+            const int cn = more ? c + 1 : 0;
+            const unsigned pvn = voff_of(primary(), tgt.z0, tgt.y0, tgt.x0, false);
+            uint4 xr[R];          // operand ring: fragment of step s lives in xr[s % R]
+            uint4 wb[3][2];       // weight fragments (dz, cout half) of the current pair / chain kinds
+            auto wfrag = [&](int f) { return wlds[f * 64 + lane]; };
+            auto xread = [&](auto S) {
+                constexpr int s = decltype(S)::value;
+                constexpr int which = x_col(s), off = x_off(s);
+                return lds[(which == 0 ? colH : which == 1 ? col1 : colP) + off];
+            };
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) wb[dz][t] = wfrag(dz * 2 + t);
+            static_for<0, D>([&](auto S) { xr[decltype(S)::value % R] = xread(S); });
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, NS>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                if constexpr (s + D < NS) xr[(s + D) % R] = xread(std::integral_constant<int, s + D>{});
+                if constexpr (s < NITEMS + WITEMS) {
+                    if (pre) load_piece(csn, cn, tgt.z0, tgt.y0, tgt.x0, pvn, s);
+                }
+                if constexpr (s < NSAME) {
+                    constexpr int pair = s / (2 * HZ), p = (s % (2 * HZ)) / 2, v = s % 2;
+                    // weight slot dz is free once plane dz + TZ - 1 is done: the next pair's
+                    // fragments (after the last pair: chain kinds 0 and 2) move in
+                    if constexpr (v == 0 && p >= TZ) {
+                        constexpr int dz = p - TZ;    // 0 or 1
+                        constexpr int f = pair < 3 ? (pair + 1) * 6 + dz * 2 : 24 + (dz == 0 ? 0 : 2) * 2;
+                        wb[dz][0] = wfrag(f);
+                        wb[dz][1] = wfrag(f + 1);
+                    }
+                    if constexpr (v == 0 && p == 0 && pair > 0) {
+                        wb[2][0] = wfrag(pair * 6 + 4);
+                        wb[2][1] = wfrag(pair * 6 + 5);
+                    }
+                    if constexpr (p >= 0 && p < TZ) {
+                        mma16<Tag>(acc[p][v][0], wb[0][0], xr[s % R]);
+                        mma16<Tag>(acc[p][v][1], wb[0][1], xr[s % R]);
+                    }
+                    if constexpr (p - 1 >= 0 && p - 1 < TZ) {
+                        mma16<Tag>(acc[p - 1][v][0], wb[1][0], xr[s % R]);
+                        mma16<Tag>(acc[p - 1][v][1], wb[1][1], xr[s % R]);
+                    }
+                    if constexpr (p - 2 >= 0 && p - 2 < TZ) {
+                        mma16<Tag>(acc[p - 2][v][0], wb[2][0], xr[s % R]);
+                        mma16<Tag>(acc[p - 2][v][1], wb[2][1], xr[s % R]);
+                    }
+                } else if constexpr (s < NSAME + TZ) {
+                    // chain, first pass: [X(p); X(p+1)] -> out p (kind 0, wb[0]) and p + 1 (kind 2, wb[1])
+                    constexpr int c1 = s - NSAME, p = (c1 / 2) * 2, v = c1 % 2;
+                    if constexpr (c1 == 0) {   // kind 1 for the second pass: wb[2] is free since the last pair ended
+                        wb[2][0] = wfrag(24 + 1 * 2);
+                        wb[2][1] = wfrag(24 + 1 * 2 + 1);
+                    }
+                    mma16<Tag>(acc[p][v][0], wb[0][0], xr[s % R]);
+                    mma16<Tag>(acc[p][v][1], wb[0][1], xr[s % R]);
+                    if constexpr (c1 == TZ - 1) {   // last use of kind 0: kind 3 takes its registers
+                        wb[0][0] = wfrag(24 + 3 * 2);
+                        wb[0][1] = wfrag(24 + 3 * 2 + 1);
+                    }
+                    mma16<Tag>(acc[p + 1][v][0], wb[1][0], xr[s % R]);
+                    mma16<Tag>(acc[p + 1][v][1], wb[1][1], xr[s % R]);
+                } else {
+                    // chain, second pass: [X(p); X(p+1)], p = 2, 4, .. -> out p - 2 (kind 1, wb[2]) and
+                    // p - 1 (kind 3, wb[0])
+                    constexpr int c2 = s - NSAME - TZ, p = (c2 / 2) * 2 + 2, v = c2 % 2;
+                    mma16<Tag>(acc[p - 2][v][0], wb[2][0], xr[s % R]);
+                    mma16<Tag>(acc[p - 2][v][1], wb[2][1], xr[s % R]);
+                    mma16<Tag>(acc[p - 1][v][0], wb[0][0], xr[s % R]);
+                    mma16<Tag>(acc[p - 1][v][1], wb[0][1], xr[s % R]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            __syncthreads();   // every wave is done reading this chunk's image
+            if (more) {
+                stage_store();
+                __syncthreads();
+            }
+        }
+
+        const int row0 = wave * 2;     // the wave's rows inside the tile
+        if (HEAD > 0) {
+            // ---- fused head: OutConv 1x1x1 (+ sigmoid) on the accumulators -----------
+            // a lane holds 8 of its voxel's 32 channels (16 t + 4 quarter + k): partial dot
+            // products, completed over the four lane quarters
+            const size_t plane = (size_t)a.h * a.w;
+#pragma unroll
+            for (int z = 0; z < TZ; ++z) {
+                const int gz = cur.z0 + z;
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const int gy = cur.y0 + row0 + v, gx = cur.x0 + lx;
+                    const bool ok = gz < a.org[0] + a.ext[0] && gy < a.org[1] + a.ext[1] &&
+                                    gx < a.org[2] + a.ext[2];
+                    float part[HEAD > 0 ? HEAD : 1];
+#pragma unroll
+                    for (int o = 0; o < HEAD; ++o) part[o] = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const float v0 = leaky(acc[z][v][t][0], a.slope), v1 = leaky(acc[z][v][t][1], a.slope);
+                        const float v2 = leaky(acc[z][v][t][2], a.slope), v3 = leaky(acc[z][v][t][3], a.slope);
+#pragma unroll
+                        for (int o = 0; o < HEAD; ++o) {
+                            const float4 hw = *reinterpret_cast<const float4*>(head_s + o * 32 + 16 * t + 4 * quarter);
+                            part[o] = fmaf(v3, hw.w, fmaf(v2, hw.z, fmaf(v1, hw.y, fmaf(v0, hw.x, part[o]))));
+                        }
+                    }
+#pragma unroll
+                    for (int o = 0; o < HEAD; ++o) {
+                        float s1 = part[o] + __shfl_xor(part[o], 16);
+                        float tsum = s1 + __shfl_xor(s1, 32) + head_s[HEAD * 32 + o];
+                        if (a.head_sigmoid) tsum = 1.f / (1.f + expf(-tsum));
+                        // outputs are dealt to the lane quarters so all of them store
+                        if (ok && o == quarter)
+                            a.head_out[(((size_t)cur.nb * HEAD + o) * a.d + gz) * plane + (size_t)gy * a.w + gx] = tsum;
+                    }
+                }
+            }
+        } else {
+            // ---- epilogue: LeakyReLU, transposed through LDS (as in conv3x3x3_zpipe) --------
+            constexpr int CPT = RECB / 32;
+            constexpr int TB_MAX = LDS_UNITS * 16 / (NWAVES * 32 * RECP);
+            constexpr int TB = POOL ? ((TB_MAX >= TZ ? TZ : TB_MAX) & ~1)
+                                    : (TB_MAX >= TZ ? TZ : (TB_MAX >= (TZ + 1) / 2 ? (TZ + 1) / 2 : 1));
+            static_assert(!POOL || (TB >= 2 && TZ % 2 == 0 && TY % 2 == 0), "pooled tile shape");
+            char* wl = reinterpret_cast<char*>(lds) + wave * (TB * 32 * RECP);
+            char* const dplane = static_cast<char*>(a.dst) +
+                                 ((size_t)cur.nb * (a.cout / KC) + ntile0 * CPT) * patch_vox * 32;
+            const int vv = lane >> 1, sub = lane & 1;
+            const int po = wave * 32 + vv;
+            const int ogy = cur.y0 + po / TX, ogx = cur.x0 + po % TX;
+#pragma unroll
+            for (int zb = 0; zb < TZ; zb += TB) {
+#pragma unroll
+                for (int z = zb; z < zb + TB && z < TZ; ++z) {
+#pragma unroll
+                    for (int v = 0; v < 2; ++v)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const int rr = v * 16 + lx, cl = 16 * t + 4 * quarter;
+                            store4<Tag>(wl + (z - zb) * (32 * RECP), (size_t)(rr * RECP) / ES + cl,
+                                        leaky(acc[z][v][t][0], a.slope), leaky(acc[z][v][t][1], a.slope),
+                                        leaky(acc[z][v][t][2], a.slope), leaky(acc[z][v][t][3], a.slope));
+                        }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int z = zb; z < zb + TB && z < TZ; ++z) {
+                    const int gz = cur.z0 + z;
+                    const bool ok = gz < a.org[0] + a.ext[0] && ogy < a.org[1] + a.ext[1] && ogx < a.org[2] + a.ext[2];
+                    const size_t vox = ((size_t)gz * a.h + ogy) * a.w + ogx;
+#pragma unroll
+                    for (int ck = 0; ck < CPT; ++ck) {
+                        const uint4 val = *reinterpret_cast<const uint4*>(
+                            wl + (z - zb) * (32 * RECP) + vv * RECP + (ck * 2 + sub) * 16);
+                        if (ok) *reinterpret_cast<uint4*>(dplane + ((size_t)ck * patch_vox + vox) * 32 + sub * 16) = val;
+                    }
+                }
+                if (POOL) {
+                    constexpr int NP = (TB / 2) * 8 * CPT * 2;
+                    const int pd = a.d >> 1, ph = a.h >> 1, pw2 = a.w >> 1;
+                    const size_t pvox = (size_t)pd * ph * pw2;
+                    char* const pplane = static_cast<char*>(a.pool_dst) +
+                                         ((size_t)cur.nb * (a.cout / KC) + ntile0 * CPT) * pvox * 32;
+#pragma unroll
+                    for (int p0 = 0; p0 < NP; p0 += 64) {
+                        const int p = p0 + lane;
+                        const int zp = p / (8 * CPT * 2), rem = p % (8 * CPT * 2);
+                        const int ck = rem / 16, xp = (rem % 16) >> 1, sb = rem & 1;
+                        if (p < NP && zb + 2 * zp + 1 < TZ) {
+                            const char* rec = wl + (2 * zp) * (32 * RECP) + (2 * xp) * RECP + (ck * 2 + sb) * 16;
+                            uint4 m = key16(*reinterpret_cast<const uint4*>(rec));
+#pragma unroll
+                            for (int k = 1; k < 8; ++k) {
+                                const uint4 vq = *reinterpret_cast<const uint4*>(
+                                    rec + (k >> 2) * (32 * RECP) + ((k >> 1) & 1) * 16 * RECP + (k & 1) * RECP);
+                                m = maxkey16(m, key16(vq));
+                            }
+                            m = key16(m);
+                            const int qz = (cur.z0 + zb) / 2 + zp, qy = cur.y0 / 2 + wave, qx = cur.x0 / 2 + xp;
+                            if (qz < pd && qy < ph && qx < pw2)
+                                *reinterpret_cast<uint4*>(pplane + ((size_t)ck * pvox +
+                                                                    ((size_t)qz * ph + qy) * pw2 + qx) * 32 + sb * 16) = m;
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (!has_next) break;
+        if (HEAD == 0) __syncthreads();   // the transposition buffers are free again
+        stage_store();
+        tile_id += t_step;
+        cur = nxt;
+    }
+}
+
 #ifdef EXASPIM_TRACE
 int g_variant = 0;   // tools/conv_trace.hip: 3/5/6 = operand prefetch distance, +10 = one tile per workgroup
 #endif
@@ -916,6 +1411,57 @@ static int launch_zpipe(const ConvArgs& a, hipStream_t stream) {
     conv3x3x3_zpipe<Tag, TZ, TY, TX, MINW, D, HEAD, POOL><<<grid, TY * TX * 2, 0, stream>>>(a, tz, ty, tx);
     EXA_CHECK_HIP(hipGetLastError());
     return EXASPIM_OK;
+}
+
+template <typename Tag, int TZ, int D, int HEAD = 0, bool POOL = false>
+static int launch_zpair(const ConvArgs& a, hipStream_t stream) {
+    constexpr int TY = 8, TX = 16, MINW = 2;
+    const int tz = (a.ext[0] + TZ - 1) / TZ, ty = (a.ext[1] + TY - 1) / TY, tx = (a.ext[2] + TX - 1) / TX;
+    const long long blocks = (long long)tz * ty * tx * a.n;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) {
+        set_error("conv: grid of %lld blocks out of range", blocks);
+        return EXASPIM_E_INVALID;
+    }
+    const int slices = a.cout / 32;
+    long long wgs = resident_workgroups(MINW) / slices / 8 * 8;
+    if (wgs < 8) wgs = 8;
+    if (wgs > blocks) wgs = blocks;
+    dim3 grid((unsigned)wgs, slices);
+    conv3x3x3_zpair<Tag, TZ, TY, MINW, D, HEAD, POOL><<<grid, TY * TX * 2, 0, stream>>>(a, tz, ty, tx);
+    EXA_CHECK_HIP(hipGetLastError());
+    return EXASPIM_OK;
+}
+
+template <typename Tag, int TZ>
+static int launch_zpair_head(const ConvArgs& a, hipStream_t stream) {
+    if (a.head_out && a.cout == 32) {
+        switch (a.head_oc) {
+            case 1: return launch_zpair<Tag, TZ, 4, 1>(a, stream);
+            case 2: return launch_zpair<Tag, TZ, 4, 2>(a, stream);
+            case 3: return launch_zpair<Tag, TZ, 4, 3>(a, stream);
+            case 4: return launch_zpair<Tag, TZ, 4, 4>(a, stream);
+        }
+    }
+    if (a.pool_dst) return launch_zpair<Tag, TZ, 4, 0, true>(a, stream);
+    return launch_zpair<Tag, TZ, 4>(a, stream);
+}
+
+// the 16x16x32 z-column kernel exists for the 16-bit types only
+template <typename Tag> struct HasPaired { static constexpr bool value = true; };
+template <> struct HasPaired<F32Tag> { static constexpr bool value = false; };
+
+// EXASPIM_ZPAIR=1 routes the 32-cout-slice layers of the 16-bit modes to conv3x3x3_zpair. Off by
+// default: measured on MI355X it is not faster than conv3x3x3_zpipe (stand-alone 0.773 vs 0.754 ms
+// on the inc.3 shape, 1.369 vs 1.334 ms on the up4.0 shape; a 1024^3 step 1.505 vs 1.476 s), and its
+// sums are associated differently from the thin-tile kernel's, so the trimmed forward would no
+// longer match the full one bit for bit next to the thin remainders.
+static bool paired_enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("EXASPIM_ZPAIR");
+        on = e && e[0] == '1';
+    }
+    return on != 0;
 }
 
 // Split-K reduction: adds the float32 partial sums of the chunk ranges in range order, then
@@ -1031,6 +1577,12 @@ static int launch_typed(const ConvArgs& a, hipStream_t stream) {
         if (g_variant >= 20) return launch_zpipe_d<Tag, 6>(a, stream);
 #endif
         if (a.cout % 64 != 0) {
+            if constexpr (HasPaired<Tag>::value) {
+                if (a.weights_paired && paired_enabled()) {
+                    if (a.d % 6 == 0) return launch_zpair_head<Tag, 6>(a, stream);
+                    return launch_zpair_head<Tag, 4>(a, stream);
+                }
+            }
             // 6-plane tiles when the depth divides (96, 48, 24): more dz reuse per LDS read
             if (a.d % 6 == 0) return launch_zpipe_d<Tag, 6>(a, stream);
             return launch_zpipe_d<Tag, 4>(a, stream);

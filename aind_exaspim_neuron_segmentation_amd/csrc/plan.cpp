@@ -128,6 +128,11 @@ bool make_plan(const int32_t channels[5], int32_t out_channels, int32_t dtype,
         woff = align_up(woff + (size_t)27 * (L.ca + L.cb) * L.cout * es, 256);
         L.b_off = woff;
         woff = align_up(woff + (size_t)L.cout * sizeof(float), 256);
+        // 32-cout-slice layers of the 16-bit modes also get the paired-tap order
+        if (dtype != EXASPIM_DT_F32 && L.cout % 64 != 0) {
+            L.w2_off = woff;
+            woff = align_up(woff + (size_t)kPairedFrags * 1024 * ((L.ca + L.cb) / 16) * (L.cout / 32), 256);
+        }
     }
     p.head_p_off = poff;
     poff += (size_t)out_channels * c[0] + out_channels;
@@ -240,6 +245,45 @@ int pack_weights(const UNetPlan& plan, const float* params, void* packed_host) {
                             }
                         }
                     }
+    }
+
+    // paired-tap fragments [chunk][frag 32][32-cout slice][lane 64][8 x 16 bit]: lane l holds
+    // cout 16 t + l % 16 and channels 8 * ((l / 16) % 2) .. + 7 of tap (l / 32 ? tap1 : tap0)
+    for (int i = 0; i < kNumMfmaConvs; ++i) {
+        const ConvLayer& L = plan.conv[i];
+        if (!L.w2_off) continue;
+        const int cin_real = L.ca_real + L.cb_real;
+        const float* blk = params + L.p_off;
+        Folded f = fold_bn(blk, L.cout_real, cin_real);
+        const int nchunks = (L.ca + L.cb) / 16, ntiles = L.cout / 32;
+        for (int c = 0; c < nchunks; ++c)
+            for (int fr = 0; fr < kPairedFrags; ++fr) {
+                int taps[2];
+                paired_frag_taps(fr, &taps[0], &taps[1]);
+                const int t16 = fr % 2;
+                for (int n = 0; n < ntiles; ++n)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int co = 32 * n + 16 * t16 + (lane & 15);
+                        const int tap = taps[lane >> 5];
+                        const size_t frag = (((size_t)c * kPairedFrags + fr) * ntiles + n) * 64 + lane;
+                        for (int j = 0; j < 8; ++j) {
+                            const int pc = 16 * c + 8 * ((lane >> 4) & 1) + j;
+                            int ci = -1;
+                            if (pc < L.ca) {
+                                if (pc < L.ca_real) ci = pc;
+                            } else {
+                                const int q = pc - L.ca;
+                                if (q < L.cb_real) ci = L.ca_real + q;
+                            }
+                            float v = 0.f;
+                            if (tap >= 0 && ci >= 0 && co < L.cout_real)
+                                v = (float)((double)blk[((size_t)co * cin_real + ci) * 27 + tap] * f.scale[co]);
+                            const uint16_t hbits = plan.dtype == EXASPIM_DT_BF16 ? f32_to_bf16_rne(v)
+                                                                                  : f32_to_f16_rne(v);
+                            std::memcpy(out + L.w2_off + (frag * 8 + j) * 2, &hbits, 2);
+                        }
+                    }
+            }
     }
 
     if (plan.convt) {

@@ -631,3 +631,35 @@ def test_predict_rejects_what_float32_cannot_carry(dev):
         inference.predict(vol.astype(np.complex64), model, **kw)
     with pytest.raises(OverflowError):          # numpy's own refusal (inference.py:79)
         inference.predict((vol % 251).astype(np.uint8), model, brightness_clip=1000, **kw)
+
+
+def test_paired_tap_kernel_variant_matches_the_reference(dev, golden):
+    """EXASPIM_ZPAIR=1 runs the 32-cout-slice layers on conv3x3x3_zpair (v_mfma_f32_16x16x32,
+    pairs of taps per instruction, paired weight fragments of plan.cpp): the switch is read once
+    per process, so the check runs in a child process -- default-config 160^3 predict in fp16
+    against the reference's golden output, same 1e-3 bar."""
+    import os
+    import subprocess
+    import sys
+
+    code = """
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+from aind_exaspim_neuron_segmentation_amd import inference
+from aind_exaspim_neuron_segmentation_amd.machine_learning.unet3d import UNet3D
+from aind_exaspim_neuron_segmentation_amd.utils import synthetic
+g = np.load(%r, allow_pickle=False)
+sd = synthetic.synth_state_dict(3, 1, seed=1)
+m = UNet3D(output_channels=3, compute_dtype="fp16")
+m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+m.to("cuda:0").eval()
+got = inference.predict(synthetic.synth_volume((160, 160, 160), seed=0), m, batch_size=8, verbose=False)
+err = np.abs(got[:, ::5, ::5, ::5] - g["pred_sub"])
+print("zpair fp16 max %%.3e mean %%.3e" %% (err.max(), err.mean()))
+assert err.max() < 1e-3
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+       os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g6_default_160.npz"))
+    env = dict(os.environ, EXASPIM_ZPAIR="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    print(out.stdout[-400:], out.stderr[-400:])
+    assert out.returncode == 0
