@@ -342,8 +342,23 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
         a.trace[trace_rec + 15] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
                                   (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
 #endif
+    // step t of the tap loop handles tap tap_of(t) = dz * 9 + dy * 3 + dx
+    constexpr auto tap_of = [](int t) { return ZORD ? (t % 3) * 9 + t / 3 : t; };
+    // Weight ring, primed for the first PD taps of a chunk BEFORE the barriers in front of it
+    // (in the prologue next to the staging loads, later right after the previous chunk's last
+    // tap): the L2 latency of a chunk's first fragments passes under the wait for the staged
+    // image instead of after it.
+    uint4 wring[PD + 1][NT];
+    auto prime_weights = [&](int c) {
+        const uint4* wp = static_cast<const uint4*>(a.weights) + ((size_t)c * 27 * ntiles + ntile0) * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < PD; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wring[t][nt] = wp[((size_t)tap_of(t) * ntiles + nt) * 64];
+    };
     EXA_TRACE(0);
     stage_load(cbeg);
+    prime_weights(cbeg);
     EXA_TRACE(1);
     stage_store();
     __syncthreads();
@@ -352,13 +367,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
     for (int c = cbeg; c < nchunks; ++c) {
         const uint4* wp = static_cast<const uint4*>(a.weights) +
                           ((size_t)c * 27 * ntiles + ntile0) * 64 + lane;
-        // step t of the tap loop handles tap tap_of(t) = dz * 9 + dy * 3 + dx
-        constexpr auto tap_of = [](int t) { return ZORD ? (t % 3) * 9 + t / 3 : t; };
-        uint4 wring[PD + 1][NT];
-#pragma unroll
-        for (int t = 0; t < PD; ++t)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wring[t][nt] = wp[((size_t)tap_of(t) * ntiles + nt) * 64];
 
         uint4 xf[2][MT];
         {
@@ -377,6 +385,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
                     wring[(t + PD) % (PD + 1)][nt] = wp[((size_t)tap_of(t + PD) * ntiles + nt) * 64];
             }
             if (t == ISSUE_T && more) stage_load(c + 1);
+#ifdef EXASPIM_TRACE
+            // 2-chunk layers leave stamps 9..11 free: marks after taps 7, 14 and 21 of the first chunk
+            if (nchunks_all == 2 && c == cbeg && t > 0 && t % 7 == 0 && t / 7 <= 3) EXA_TRACE(8 + t / 7);
+#endif
             if (t + 1 < 27) {
                 const int tn = tap_of(t + 1);
                 const int tapoff = ((tn / 9) * HY + (tn / 3) % 3) * HXS + tn % 3;
@@ -392,6 +404,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
             // this fence hipcc hoists and sinks them across taps and the loop runs ~20 % slower
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (more) prime_weights(c + 1);
         if (c - cbeg < 4) EXA_TRACE(3 + 3 * (c - cbeg));
         __syncthreads();  // every wave is done reading this chunk's image
         if (c - cbeg < 4) EXA_TRACE(4 + 3 * (c - cbeg));
@@ -518,8 +531,12 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
     constexpr int LDS_UNITS = XUNITS + WUNITS;
     constexpr int NS = 9 * HZ;             // steps per chunk
     constexpr int R = D + 1;               // operand ring
+#ifndef EXASPIM_LOAD_STRIDE
+#define EXASPIM_LOAD_STRIDE 3              // measured 1 / 2 / 3: 0.742 / 0.725 / 0.710 ms (inc.3 shape)
+#endif
+    constexpr int LOAD_STRIDE = EXASPIM_LOAD_STRIDE * (NITEMS + WITEMS) <= NS ? EXASPIM_LOAD_STRIDE : 1;
     static_assert(TY * TX % 32 == 0 && NPAIR <= 2 * NTHREADS, "tile shape");
-    static_assert(NITEMS + WITEMS <= NS, "one staged piece per step");
+    static_assert(LOAD_STRIDE * (NITEMS + WITEMS) <= NS, "the staged pieces fit into the steps");
 
     __shared__ __attribute__((aligned(16))) uint4 lds[LDS_UNITS];
 
@@ -745,9 +762,18 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
                     const int g2 = (s + D) / HZ, z2 = (s + D) % HZ;
                     xr[(s + D) % R] = lds[col + z2 * PLANE + (g2 / 3) * HXP + g2 % 3];
                 }
+#ifdef EXASPIM_TRACE
+                // 2-chunk layers leave stamps 9..11 free: quarter marks inside the first chunk's loop
+                if (nchunks == 2 && c == 0 && s > 0 && s % (NS / 4) == 0 && s / (NS / 4) <= 3) EXA_TRACE(8 + s / (NS / 4));
+#endif
                 if (g + 1 < 9 && zin >= TZ) wb[zin - TZ] = wlds[((zin - TZ) * 9 + g + 1) * 64 + lane];
                 if (g > 0 && zin == 0) wb[2] = wlds[(2 * 9 + g) * 64 + lane];
-                if (!(EXASPIM_ABLATE & 1) && pre && s < NITEMS + WITEMS) load_piece(csn, cn, zn, s);
+                // one staged piece every LOAD_STRIDE steps: issued back to back in the first steps
+                // the loads of all eight waves of a CU queue up in the texture addresser, and the
+                // MFMAs behind a load that cannot issue wait with it (the first quarter of the loop
+                // took 5.1 k cycles, the others 1.3-1.8 k; spread out 3.2 k: tools/conv_trace.hip)
+                if (!(EXASPIM_ABLATE & 1) && pre && s % LOAD_STRIDE == 0 && s / LOAD_STRIDE < NITEMS + WITEMS)
+                    load_piece(csn, cn, zn, s / LOAD_STRIDE);
 #pragma unroll
                 for (int dz = 0; dz < 3; ++dz) {
                     const int z = zin - dz;

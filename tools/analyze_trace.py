@@ -5,7 +5,7 @@ import sys
 import numpy as np
 
 
-def main(path, ms=None):
+def main(path, ms=None, nchunks=0):
     t = np.fromfile(path, dtype=np.uint64).reshape(-1, 4, 16).astype(np.int64)
     t = t[t[:, 0, 14] > 0]   # records of workgroups / tiles that ran
     nwg = t.shape[0]
@@ -18,7 +18,7 @@ def main(path, ms=None):
     cukey = ((xcc * 8 + se) * 2 + sh) * 16 + cu
     print(f"{nwg} workgroups, {len(np.unique(cukey[:, 0]))} CUs seen, simds of waves 0..3 (first WG): {simd[0]}")
     ev = t[:, :, :15]
-    nch = 1 + max(c for c in range(4) if (ev[:, 0, 3 + 3 * c] > 0).all())
+    nch = nchunks or 1 + max(c for c in range(4) if (ev[:, 0, 3 + 3 * c] > 0).all())
     span = ev[:, :, 14].max() - ev[:, :, 0].min()
     print(f"chunks {nch}; stamp span {span} ticks" + (f" = {span / (ms * 1e3):.1f} ticks/us" if ms else ""))
 
@@ -37,6 +37,10 @@ def main(path, ms=None):
             stat(f"chunk {c}: store + barrier 2", ev[:, :, 5 + 3 * c] - ev[:, :, 4 + 3 * c])
             prev = ev[:, :, 5 + 3 * c]
     stat("epilogue", ev[:, :, 14] - ev[:, :, 4 + 3 * (nch - 1)])
+    if nch == 2 and (ev[:, 0, 9] > 0).all():   # quarter marks inside the first chunk's tap loop
+        marks = [ev[:, :, 2], ev[:, :, 9], ev[:, :, 10], ev[:, :, 11], ev[:, :, 3]]
+        for q in range(4):
+            stat(f"chunk 0 loop, quarter {q}", marks[q + 1] - marks[q])
 
     # per-CU occupancy: time with k workgroups resident / in their tap loops
     res_frac = np.zeros(4)
@@ -74,4 +78,5 @@ def main(path, ms=None):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else None)
+    main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 and float(sys.argv[2]) > 0 else None,
+         int(sys.argv[3]) if len(sys.argv) > 3 else 0)
