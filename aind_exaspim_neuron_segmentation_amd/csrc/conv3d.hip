@@ -532,7 +532,9 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
     constexpr int NS = 9 * HZ;             // steps per chunk
     constexpr int R = D + 1;               // operand ring
 #ifndef EXASPIM_LOAD_STRIDE
-#define EXASPIM_LOAD_STRIDE 3              // measured 1 / 2 / 3: 0.742 / 0.725 / 0.710 ms (inc.3 shape)
+// stride 1 / 2 / 3 inside a 1024^3 step (us per launch, same box): up3.3 + up4.0 510 / 490 / 496,
+// inc.3 831 / 801 / 801, up4.3 with the fused head 514 / 496 / 536
+#define EXASPIM_LOAD_STRIDE 2
 #endif
     constexpr int LOAD_STRIDE = EXASPIM_LOAD_STRIDE * (NITEMS + WITEMS) <= NS ? EXASPIM_LOAD_STRIDE : 1;
     static_assert(TY * TX % 32 == 0 && NPAIR <= 2 * NTHREADS, "tile shape");
