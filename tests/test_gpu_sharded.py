@@ -96,3 +96,36 @@ def test_sharded_predict_matches_single_process(world):
         msgs.append(failures.get())
     assert not msgs, msgs
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` (the driver's command form) must start the N ranks itself:
+    the parent spawns the children before it touches the GPU and relays a non-zero exit.
+    Rehearsed here with 2 ranks sharing the one GPU over gloo on a small volume; rank 0 prints
+    the JSON line with the contract fields, a config-faithful workload string and exchange_ms."""
+    import json
+    import subprocess
+    import sys
+
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EXASPIM_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run(
+        [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--size", "128", "--steps", "1",
+         "--warmup", "0", "--no-cpu-baseline"],
+        env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["unit"] == "voxels/s" and d["value"] > 0
+    assert "256x128x128" in d["metric"] and "256x128x128" in d["config"]["workload"]
+    assert d["config"]["rank_grid_zy"] == [2, 1] and d["config"]["exchange_ms"] >= 0
+    assert d["roofline"]["timed_launches"] > 0 and "cpu_baseline" not in d
+    # a failing rank makes the launcher exit non-zero
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--size", "16"],   # no patch fits: Shard raises in every rank
+                         env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert bad.returncode != 0
