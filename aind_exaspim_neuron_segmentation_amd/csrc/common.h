@@ -75,6 +75,8 @@ struct ConvLayer {
     size_t w_off = 0;              // packed weights (compute dtype), bytes
     size_t w2_off = 0;             // the same weights in paired-tap fragment order (16-bit modes,
                                    // 32-cout-slice layers: conv3x3x3_zpair), 0 if not packed
+    size_t w3_off = 0;             // the same weights as K = 32 fragments for conv3x3x3_t16 (16-bit modes,
+                                   // the 64-cout-slice layers of pyramid level 1), 0 if not packed
     size_t b_off = 0;              // folded bias, float[cout], bytes
     size_t p_off = 0;              // offset of this conv's block in params
 };
@@ -119,6 +121,7 @@ struct ConvArgs {
     int ca, cb;          // padded channel counts of the two sources (cb may be 0)
     const void* weights; // packed fragments
     const void* weights_paired = nullptr;   // paired-tap fragments (ConvLayer::w2_off), or null
+    const void* weights_k32 = nullptr;      // K = 32 fragments (ConvLayer::w3_off), or null
     const float* bias;
     void* dst;
     int cout;            // padded

@@ -211,8 +211,14 @@ __device__ __forceinline__ void store4<F16Tag>(void* dst, size_t off, float a, f
 // ZORD: walk the 27 taps in the z-column kernel's order (in-plane tap outermost, dz
 // innermost) instead of dz-major, so that a voxel gets the same bits from either kernel
 // (the thin remainders of a region next to z-column tiles).
+// DMA: the halo image is double-buffered and filled by LDS-DMA (buffer_load ... lds, 1 KiB per
+// wave-instruction = 64 consecutive slots of one channel-group plane): the next chunk lands in
+// the other buffer while this one is read, nothing is staged through registers, no ds_write,
+// one barrier per chunk instead of two. The DMA is issued as inline assembly -- through the
+// builtin hipcc puts a vmcnt(0) wait in front of every later LDS read, because it cannot see
+// that they touch the other buffer -- and waited for explicitly before the chunk's barrier.
 template <typename Tag, int TZ, int TY, int TX, int WAVES_M, int WAVES_N, int MT, int NT, int MINW, int PD,
-          bool ZORD = false>
+          bool ZORD = false, bool DMA = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
     ConvArgs a, int tiles_z, int tiles_y, int tiles_x) {
     constexpr int G = Tag::kG;
@@ -225,7 +231,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
     // cycles 50 % -> 17 % of the LDS-active cycles, which drop by 39 %; the launch time
     // does not move, LDS is not what limits this kernel). Padding is never touched.
     constexpr int HXS = TX == 24 ? 40 : HX;
-    constexpr int HV = HZ * HY * HXS;               // slots per channel-group plane
+    constexpr int HVR = HZ * HY * HXS;              // slots of a channel-group plane that hold voxels
+    // plane stride: with DMA a plane is written in whole 64-slot blocks (the tail lanes write zeros)
+    constexpr int HV = DMA ? (HVR + 63) / 64 * 64 : HVR;
     constexpr int HVD = HZ * HY * HX;               // halo voxels (staging enumerates these)
     constexpr int NWAVES = WAVES_M * WAVES_N;
     constexpr int NTHREADS = NWAVES * 64;
@@ -234,7 +242,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
     constexpr int RECB = NT * 32 * ES;              // bytes of one voxel's output slice
     constexpr int RECP = RECB + 16;                 // padded LDS stride (8-way -> 2-way conflicts)
     constexpr int EPI_UNITS = NWAVES * 32 * RECP / 16;
-    constexpr int LDS_UNITS = 2 * HV > EPI_UNITS ? 2 * HV : EPI_UNITS;
+    constexpr int IMG = 2 * HV;                     // slots of one image (two channel groups)
+    constexpr int LDS_UNITS = (DMA ? 2 : 1) * IMG > EPI_UNITS ? (DMA ? 2 : 1) * IMG : EPI_UNITS;
+    constexpr int NBLK = HV / 64;                   // DMA: 64-slot blocks per plane
+    constexpr int NDMA = DMA ? (2 * NBLK + NWAVES - 1) / NWAVES : 1;   // blocks per wave and image
+    static_assert(!DMA || HXS == HX, "DMA staging wants dense rows");
     constexpr int ISSUE_T = 26 - PD > 0 ? 26 - PD : 0;  // tap at which the prefetch is issued
     static_assert(WAVES_M * MT * 32 >= TILE_VOX, "tile not covered by the waves");
 
@@ -290,6 +302,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
         voffs[it] = ok ? (unsigned)((gz * a.h + gy) * a.w + gx) * 32u + (i & 1) * 16u : kOutOfRange;
     }
 
+    // DMA block j = wave + k * NWAVES of an image: plane (group) j / NBLK, slots (j % NBLK) * 64 + lane
+    unsigned dvoff[NDMA];
+    if (DMA) {
+#pragma unroll
+        for (int k = 0; k < NDMA; ++k) {
+            const int j = wave + k * NWAVES;
+            const int g = j / NBLK, slot = (j % NBLK) * 64 + lane;
+            const int hz = slot / (HY * HX), hy = (slot / HX) % HY, hx = slot % HX;
+            const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+            const bool ok = j < 2 * NBLK && slot < HVR && (unsigned)gz < (unsigned)a.d &&
+                            (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
+            dvoff[k] = ok ? (unsigned)((gz * a.h + gy) * a.w + gx) * 32u + g * 16u : kOutOfRange;
+        }
+    }
+
     // accumulators start from the folded bias: register 4q+k of a lane is channel
     // 8q + 4*half + k of its slice (no bias pass in the epilogue)
     f32x16 acc[MT][NT];
@@ -336,6 +363,31 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
         }
     };
 
+    // chunk c -> image buffer "buf", by LDS-DMA (this wave's blocks)
+    const unsigned lds_base = (unsigned)(size_t)lds;
+    auto dma_load = [&](int c, int buf) {
+        const char* src;
+        int cs, ch0;
+        if (c * KC < a.ca) {
+            src = static_cast<const char*>(a.src_a); cs = a.ca; ch0 = c * KC;
+        } else {
+            src = static_cast<const char*>(a.src_b); cs = a.cb; ch0 = c * KC - a.ca;
+        }
+        const size_t patchb = patch_vox * cs * ES;
+        const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(src + (size_t)nb * patchb, patchb);
+        const unsigned cbase = (unsigned)(ch0 / KC) * (unsigned)patch_vox * 32u;
+#pragma unroll
+        for (int k = 0; k < NDMA; ++k) {
+            const int j = wave + k * NWAVES;
+            if (j < 2 * NBLK) {   // wave-uniform
+                const unsigned dst = __builtin_amdgcn_readfirstlane(
+                    lds_base + (unsigned)((buf * IMG + (j / NBLK) * HV + (j % NBLK) * 64) * 16));
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                             :: "s"(dst), "v"(dvoff[k]), "s"(rsrc), "s"(cbase) : "memory");   // m0 is not allocatable: nothing of the compiler's lives in it
+            }
+        }
+    };
+
 #ifdef EXASPIM_TRACE
     const size_t trace_rec = ((size_t)blockIdx.x * NWAVES + wave) * 16;
     if (a.trace && lane == 0)
@@ -357,10 +409,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
             for (int nt = 0; nt < NT; ++nt) wring[t][nt] = wp[((size_t)tap_of(t) * ntiles + nt) * 64];
     };
     EXA_TRACE(0);
-    stage_load(cbeg);
+    if (DMA) dma_load(cbeg, 0); else stage_load(cbeg);
     prime_weights(cbeg);
     EXA_TRACE(1);
-    stage_store();
+    if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else stage_store();
     __syncthreads();
     EXA_TRACE(2);
 
@@ -368,12 +420,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
         const uint4* wp = static_cast<const uint4*>(a.weights) +
                           ((size_t)c * 27 * ntiles + ntile0) * 64 + lane;
 
+        // DMA: chunks alternate between the two image buffers
+        const int cur = DMA ? (c - cbeg) & 1 : 0;
+        const uint4* const img = lds + cur * IMG;
         uint4 xf[2][MT];
         {
             constexpr int t0 = tap_of(0);
             constexpr int tapoff0 = ((t0 / 9) * HY + (t0 / 3) % 3) * HXS + t0 % 3;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) xf[0][mt] = lds[base[mt] + tapoff0];
+            for (int mt = 0; mt < MT; ++mt) xf[0][mt] = img[base[mt] + tapoff0];
         }
 
         const bool more = c + 1 < nchunks;
@@ -384,7 +439,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
                 for (int nt = 0; nt < NT; ++nt)
                     wring[(t + PD) % (PD + 1)][nt] = wp[((size_t)tap_of(t + PD) * ntiles + nt) * 64];
             }
-            if (t == ISSUE_T && more) stage_load(c + 1);
+            if (t == ISSUE_T && more) {
+                if (DMA) dma_load(c + 1, cur ^ 1); else stage_load(c + 1);
+            }
 #ifdef EXASPIM_TRACE
             // 2-chunk layers leave stamps 9..11 free: marks after taps 7, 14 and 21 of the first chunk
             if (nchunks_all == 2 && c == cbeg && t > 0 && t % 7 == 0 && t / 7 <= 3) EXA_TRACE(8 + t / 7);
@@ -393,7 +450,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
                 const int tn = tap_of(t + 1);
                 const int tapoff = ((tn / 9) * HY + (tn / 3) % 3) * HXS + tn % 3;
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) xf[(t + 1) & 1][mt] = lds[base[mt] + tapoff];
+                for (int mt = 0; mt < MT; ++mt) xf[(t + 1) & 1][mt] = img[base[mt] + tapoff];
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -406,12 +463,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
         }
         if (more) prime_weights(c + 1);
         if (c - cbeg < 4) EXA_TRACE(3 + 3 * (c - cbeg));
-        __syncthreads();  // every wave is done reading this chunk's image
-        if (c - cbeg < 4) EXA_TRACE(4 + 3 * (c - cbeg));
-        if (more) {
-            stage_store();
+        if (DMA) {
+            // this wave's DMA blocks (and the primed weights) have landed; behind the barrier so have
+            // everyone's, and everyone is done reading this chunk's buffer
+            if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (c - cbeg < 3) EXA_TRACE(5 + 3 * (c - cbeg));
+            if (c - cbeg < 4) EXA_TRACE(4 + 3 * (c - cbeg));
+            if (more && c - cbeg < 3) EXA_TRACE(5 + 3 * (c - cbeg));
+        } else {
+            __syncthreads();  // every wave is done reading this chunk's image
+            if (c - cbeg < 4) EXA_TRACE(4 + 3 * (c - cbeg));
+            if (more) {
+                stage_store();
+                __syncthreads();
+                if (c - cbeg < 3) EXA_TRACE(5 + 3 * (c - cbeg));
+            }
         }
     }
 
@@ -976,6 +1042,21 @@ __device__ __forceinline__ void mma16<F16Tag>(f32x4& acc, const uint4& wf, const
                  : "+v"(acc) : "v"(__builtin_bit_cast(u32x4, wf)), "v"(__builtin_bit_cast(u32x4, xf)));
 }
 
+// The same with the accumulator in the accumulation register file: for one-wave-per-SIMD
+// kernels, whose 128 accumulators would otherwise crowd the operands out of the 256 VGPRs.
+template <typename Tag>
+__device__ __forceinline__ void mma16_agpr(f32x4& acc, const uint4& wf, const uint4& xf);
+template <>
+__device__ __forceinline__ void mma16_agpr<BF16Tag>(f32x4& acc, const uint4& wf, const uint4& xf) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+                 : "+a"(acc) : "v"(__builtin_bit_cast(u32x4, wf)), "v"(__builtin_bit_cast(u32x4, xf)));
+}
+template <>
+__device__ __forceinline__ void mma16_agpr<F16Tag>(f32x4& acc, const uint4& wf, const uint4& xf) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0"
+                 : "+a"(acc) : "v"(__builtin_bit_cast(u32x4, wf)), "v"(__builtin_bit_cast(u32x4, xf)));
+}
+
 template <typename Tag, int TZ, int TY, int MINW, int D, int HEAD = 0, bool POOL = false>
 __global__ __launch_bounds__(TY * 16 * 2, MINW) void conv3x3x3_zpair(
     ConvArgs a, int tiles_z, int tiles_y, int tiles_x) {
@@ -1400,6 +1481,223 @@ __global__ __launch_bounds__(TY * 16 * 2, MINW) void conv3x3x3_zpair(
     }
 }
 
+// ---- conv3x3x3_t16: 64-cout layers on v_mfma_f32_16x16x32 (16-bit modes, 16-wide levels) ------
+// Under the package power cap the 16x16x32 shape sustains ~15 % more FLOP/s than 32x32x16 at
+// equal operand traffic (tools/mfma_shape.hip). Its K is 32 = two 16-channel chunks, so the LDS
+// image holds a PAIR of chunks (four 16-byte channel-group planes); double-buffered and filled by
+// LDS-DMA that is 2 x 69.6 KB, i.e. one workgroup of four waves per CU with the whole register
+// file (512 per lane) to itself. With nobody else on the CU to hide a prologue or an epilogue
+// behind, the workgroup is persistent: the image of the next tile's first pair is fetched during
+// the last pair of the current tile, and the epilogue goes through a small private LDS region
+// per wave, so the MFMA pipe only idles for the epilogue's own instructions.
+// A wave owns one z-plane of the 4 x 8 x 16 tile = 8 rows of 16 voxels (8 B fragments per tap
+// and pair, each one ds_read_b128: lanes 16 q .. 16 q + 15 read plane q) x 64 couts (4 A
+// fragments per tap and pair, streamed from L2 through a register ring): 32 MFMAs of 16 cycles
+// per 8 + 4 operand fragments. A B fragment's register is refilled for the next tap as soon as
+// its four MFMAs have been issued. Weight fragments in the K = 32 order of plan.cpp
+// (ConvLayer::w3_off). Whole patches only (no region), cout == 64, ca and cb multiples of 32.
+template <typename Tag, int PD>
+__global__ __launch_bounds__(256, 1) void conv3x3x3_t16(ConvArgs a, int tiles_z, int tiles_y, int tiles_x) {
+    constexpr int TZ = 4, TY = 8, TX = 16;
+    constexpr int ES = 2;
+    constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+    constexpr int HVR = HZ * HY * HX;               // halo voxels = slots of a plane that hold voxels
+    constexpr int HV = (HVR + 63) / 64 * 64;        // plane stride (whole 64-slot DMA blocks)
+    constexpr int NBLK = HV / 64;
+    constexpr int IMG = 4 * HV;                     // slots of a pair image: [chunk 2][group 2][HV]
+    constexpr int NWAVES = 4;
+    constexpr int NDMA = (4 * NBLK + NWAVES - 1) / NWAVES;   // DMA blocks per wave and pair image
+    constexpr int RECB = 64 * ES;                   // bytes of one voxel's 64-cout record
+    constexpr int RECP = RECB + 16;
+    constexpr int EPI_UNITS = 32 * RECP / 16;       // per wave: two rows of 16 voxel records
+    constexpr int ISSUE_T = 26 - PD > 0 ? 26 - PD : 0;
+
+    __shared__ __attribute__((aligned(16))) uint4 lds[2 * IMG + NWAVES * EPI_UNITS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = the tile's z-plane this wave computes
+    const int quarter = lane >> 4, lx = lane & 15;
+
+    // Workgroup b runs on XCD b % 8; every XCD gets a contiguous range of tiles and its
+    // workgroups walk it side by side, so neighbouring tiles meet in the same L2.
+    const int ntiles = tiles_z * tiles_y * tiles_x * a.n;
+    const int nwg_xcd = gridDim.x >> 3;             // the launcher keeps gridDim.x a multiple of 8
+    int tile, tile_end;
+    {
+        const int q = ntiles >> 3, rem = ntiles & 7;
+        const int xcd = blockIdx.x & 7;
+        const int first = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+        tile = first + (blockIdx.x >> 3);
+        tile_end = first + (xcd < rem ? q + 1 : q);
+    }
+    if (tile >= tile_end) return;
+
+    const size_t patch_vox = (size_t)a.d * a.h * a.w;
+    const int npairs = (a.ca + a.cb) / 32;
+
+    // slot of this lane's voxel of row 0 of the wave's plane, tap (0,0,0), in plane "quarter"
+    const int xbase = quarter * HV + (wave * HY) * HX + lx;
+
+    // DMA block j = wave + k * NWAVES of a pair image: plane j / NBLK, slots (j % NBLK) * 64 + lane
+    unsigned dvoff[NDMA];
+    auto aim = [&](int t, int& nb, int& z0, int& y0, int& x0) {
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y; t /= tiles_y;
+        const int tz = t % tiles_z;
+        nb = t / tiles_z;
+        z0 = tz * TZ; y0 = ty * TY; x0 = tx * TX;
+#pragma unroll
+        for (int k = 0; k < NDMA; ++k) {
+            const int j = wave + k * NWAVES;
+            const int pl = j / NBLK, slot = (j % NBLK) * 64 + lane;
+            const int hz = slot / (HY * HX), hy = (slot / HX) % HY, hx = slot % HX;
+            const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+            const bool ok = j < 4 * NBLK && slot < HVR && (unsigned)gz < (unsigned)a.d &&
+                            (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
+            // the chunk of the pair (pl >> 1) rides in the scalar offset
+            dvoff[k] = ok ? (unsigned)((gz * a.h + gy) * a.w + gx) * 32u + (pl & 1) * 16u : kOutOfRange;
+        }
+    };
+    const unsigned lds_base = (unsigned)(size_t)lds;
+    auto dma_load = [&](int nb, int pr, int buf) {
+        const int c = 2 * pr;                       // first chunk of the pair (both in one source)
+        const char* src;
+        int cs, ch0;
+        if (c * 16 < a.ca) {
+            src = static_cast<const char*>(a.src_a); cs = a.ca; ch0 = c * 16;
+        } else {
+            src = static_cast<const char*>(a.src_b); cs = a.cb; ch0 = c * 16 - a.ca;
+        }
+        const size_t patchb = patch_vox * cs * ES;
+        const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(src + (size_t)nb * patchb, patchb);
+        const unsigned cbase = (unsigned)(ch0 / 16) * (unsigned)patch_vox * 32u;
+#pragma unroll
+        for (int k = 0; k < NDMA; ++k) {
+            const int j = wave + k * NWAVES;
+            if ((4 * NBLK) % NWAVES == 0 || j < 4 * NBLK) {   // wave-uniform
+                const int pl = j / NBLK;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(
+                    lds_base + (unsigned)((buf * IMG + pl * HV + (j % NBLK) * 64) * 16));
+                const unsigned soff = cbase + (unsigned)(pl >> 1) * (unsigned)patch_vox * 32u;
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                             :: "s"(dst), "v"(dvoff[k]), "s"(rsrc), "s"(soff) : "memory");   // m0 is not allocatable: nothing of the compiler's lives in it
+            }
+        }
+    };
+
+    uint4 wring[PD + 1][4];
+    auto weights_at = [&](int pr, int t) {
+        return static_cast<const uint4*>(a.weights_k32) + ((size_t)pr * 27 + t) * 4 * 64 + lane;
+    };
+    auto prime_weights = [&](int pr) {
+#pragma unroll
+        for (int t = 0; t < PD; ++t) {
+            const uint4* wp = weights_at(pr, t);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) wring[t][ct] = wp[ct * 64];
+        }
+    };
+
+    float4 bias4[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) bias4[ct] = *reinterpret_cast<const float4*>(a.bias + ct * 16 + 4 * quarter);
+
+    int nb, z0, y0, x0;
+    aim(tile, nb, z0, y0, x0);
+    dma_load(nb, 0, 0);
+    prime_weights(0);
+    int buf = 0;   // the LDS buffer the pair about to be computed sits in
+
+    for (;;) {
+        // accumulators: register k of acc[vg][ct] is cout 16 ct + 4 quarter + k of voxel (row vg, lx)
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int vg = 0; vg < 8; ++vg) {
+                acc[vg][ct][0] = bias4[ct].x; acc[vg][ct][1] = bias4[ct].y;
+                acc[vg][ct][2] = bias4[ct].z; acc[vg][ct][3] = bias4[ct].w;
+            }
+        const int next = tile + nwg_xcd;
+        const bool more_tiles = next < tile_end;    // workgroup-uniform
+        const int cz0 = z0, cy0 = y0, cx0 = x0, cnb = nb;
+
+        for (int pr = 0; pr < npairs; ++pr) {
+            // this wave's DMA blocks (and weights, and the last tile's stores) have landed; after
+            // the barrier so have everyone's, and nobody still reads the other buffer
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const uint4* const img = lds + buf * IMG;
+            const bool more = pr + 1 < npairs;
+            uint4 bf[8];
+#pragma unroll
+            for (int vg = 0; vg < 8; ++vg) bf[vg] = img[xbase + vg * HX];
+            static_for<0, 27>([&](auto T) {
+                constexpr int t = decltype(T)::value;
+                if constexpr (t + PD < 27) {
+                    const uint4* wp = weights_at(pr, t + PD);
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) wring[(t + PD) % (PD + 1)][ct] = wp[ct * 64];
+                }
+                if constexpr (t == ISSUE_T) {
+                    if (more) {
+                        dma_load(cnb, pr + 1, buf ^ 1);
+                    } else if (more_tiles) {
+                        aim(next, nb, z0, y0, x0);
+                        dma_load(nb, 0, buf ^ 1);
+                    }
+                }
+                constexpr int tapn = ((t + 1) / 9 * HY + ((t + 1) / 3) % 3) * HX + (t + 1) % 3;
+#pragma unroll
+                for (int vg = 0; vg < 8; ++vg) {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) mma16_agpr<Tag>(acc[vg][ct], wring[t % (PD + 1)][ct], bf[vg]);
+                    // this row's fragment of the next tap takes over the register
+                    if constexpr (t + 1 < 27) bf[vg] = img[xbase + vg * HX + tapn];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            prime_weights(more ? pr + 1 : 0);
+            buf ^= 1;
+        }
+
+        // ---- epilogue: LeakyReLU, two rows at a time transposed through the wave's LDS region ----
+        {
+            char* wl = reinterpret_cast<char*>(lds + 2 * IMG + wave * EPI_UNITS);
+            const int vv = lane >> 1, sub = lane & 1;   // a store instruction = one chunk plane's 32 records
+            const int gz = cz0 + wave;
+            char* const dplane = static_cast<char*>(a.dst) + (size_t)cnb * 4 * patch_vox * 32;
+#pragma unroll
+            for (int mg = 0; mg < 4; ++mg) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {
+                        const f32x4 v = acc[2 * mg + r][ct];
+                        store4<Tag>(wl, (size_t)((r * 16 + lx) * RECP) / ES + 16 * ct + 4 * quarter,
+                                    leaky(v[0], a.slope), leaky(v[1], a.slope), leaky(v[2], a.slope),
+                                    leaky(v[3], a.slope));
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int gy = cy0 + 2 * mg + vv / 16, gx = cx0 + vv % 16;
+                const bool ok = gz < a.d && gy < a.h && gx < a.w;
+                const size_t vox = ((size_t)gz * a.h + gy) * a.w + gx;
+#pragma unroll
+                for (int ck = 0; ck < 4; ++ck) {
+                    const uint4 val = *reinterpret_cast<const uint4*>(wl + vv * RECP + (ck * 2 + sub) * 16);
+                    if (ok) *reinterpret_cast<uint4*>(dplane + ((size_t)ck * patch_vox + vox) * 32 + sub * 16) = val;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (!more_tiles) break;
+        tile = next;
+    }
+}
+
 #ifdef EXASPIM_TRACE
 int g_variant = 0;   // tools/conv_trace.hip: 3/5/6 = operand prefetch distance, +10 = one tile per workgroup
 #endif
@@ -1523,7 +1821,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 template <typename Tag, int TZ, int TY, int TX, int WAVES_M, int WAVES_N, int MT, int NT, int MINW, int PD = 3,
-          bool ZORD = false>
+          bool ZORD = false, bool DMA = false>
 static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
     constexpr int NWG = WAVES_N * NT * 32;
     if (a.cout % NWG != 0) {
@@ -1558,7 +1856,7 @@ static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
         b.ksplit = ks;
     }
     dim3 grid((unsigned)blocks, a.cout / NWG, b.ksplit);
-    conv3x3x3_t14<Tag, TZ, TY, TX, WAVES_M, WAVES_N, MT, NT, MINW, PD, ZORD>
+    conv3x3x3_t14<Tag, TZ, TY, TX, WAVES_M, WAVES_N, MT, NT, MINW, PD, ZORD, DMA>
         <<<grid, WAVES_M * WAVES_N * 64, 0, stream>>>(b, tz, ty, tx);
     EXA_CHECK_HIP(hipGetLastError());
     if (b.ksplit > 1) {
@@ -1615,7 +1913,25 @@ static int launch_typed(const ConvArgs& a, hipStream_t stream) {
             if (a.d % 6 == 0) return launch_zpipe_d<Tag, 6>(a, stream);
             return launch_zpipe_d<Tag, 4>(a, stream);
         }
-        return launch_cfg<Tag, 4, 8, 16, 4, 1, 4, 2, 2>(a, stream);
+        if constexpr (HasPaired<Tag>::value) {
+            static int t16 = -1;
+            if (t16 < 0) { const char* e = getenv("EXASPIM_T16"); t16 = e && e[0] == '1'; }
+            const bool whole = a.ext[0] == a.d && a.ext[1] == a.h && a.ext[2] == a.w;
+            if (t16 && a.weights_k32 && whole && a.cout == 64 && a.ca % 32 == 0 && a.cb % 32 == 0) {
+                const int tz = cdiv(a.d, 4), ty = cdiv(a.h, 8), tx = cdiv(a.w, 16);
+                const int ntiles = tz * ty * tx * a.n;
+                long long nwg = resident_workgroups(1) / 8 * 8;   // one persistent workgroup per CU
+                if (nwg < 8) nwg = 8;
+                if (nwg > ntiles) nwg = (ntiles + 7) / 8 * 8;
+                conv3x3x3_t16<Tag, 2><<<(unsigned)nwg, 256, 0, stream>>>(a, tz, ty, tx);
+                EXA_CHECK_HIP(hipGetLastError());
+                return EXASPIM_OK;
+            }
+        }
+#ifndef EXASPIM_T14_DMA
+#define EXASPIM_T14_DMA 0
+#endif
+        return launch_cfg<Tag, 4, 8, 16, 4, 1, 4, 2, 2, 3, false, EXASPIM_T14_DMA != 0>(a, stream);
     }
     if (a.w > 12) {
         if (a.cout % 64 == 0) return launch_cfg<Tag, 4, 4, 24, 4, 1, 3, 2, 2>(a, stream);

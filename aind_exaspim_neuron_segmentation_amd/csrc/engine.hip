@@ -139,6 +139,7 @@ static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, in
         a.src_a = sa; a.src_b = sb; a.ca = L.ca; a.cb = L.cb;
         a.weights = e->packed + L.w_off;
         a.weights_paired = L.w2_off ? e->packed + L.w2_off : nullptr;
+        a.weights_k32 = L.w3_off ? e->packed + L.w3_off : nullptr;
         a.bias = reinterpret_cast<const float*>(e->packed + L.b_off);
         a.dst = dst; a.cout = L.cout;
         a.n = n; a.d = d >> l; a.h = h >> l; a.w = w >> l;

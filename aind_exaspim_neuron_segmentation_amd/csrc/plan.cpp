@@ -128,6 +128,12 @@ bool make_plan(const int32_t channels[5], int32_t out_channels, int32_t dtype,
         woff = align_up(woff + (size_t)27 * (L.ca + L.cb) * L.cout * es, 256);
         L.b_off = woff;
         woff = align_up(woff + (size_t)L.cout * sizeof(float), 256);
+        // level-1 layers with 64-cout slices (down1.0, down1.3, up3.0): K = 32 fragments for the
+        // 16x16x32 kernel, [pair of chunks][tap 27][16-cout group][lane 64][8 x 16 bit]
+        if (dtype != EXASPIM_DT_F32 && L.cout % 64 == 0 && (i == 1 || i == 2 || i == 13)) {
+            L.w3_off = woff;
+            woff = align_up(woff + (size_t)27 * (L.ca + L.cb) * L.cout * es, 256);
+        }
         // 32-cout-slice layers of the 16-bit modes also get the paired-tap order
         if (dtype != EXASPIM_DT_F32 && L.cout % 64 != 0) {
             L.w2_off = woff;
@@ -243,6 +249,42 @@ int pack_weights(const UNetPlan& plan, const float* params, void* packed_host) {
                                                            : f32_to_f16_rne(v);
                                 std::memcpy(dst, &hbits, 2);
                             }
+                        }
+                    }
+    }
+
+    // K = 32 fragments: lane l holds cout 16 ct + l % 16 and the 8 channels
+    // 32 pair + 16 * (l / 32) + 8 * ((l / 16) % 2) .. + 7 (pair = two consecutive 16-channel chunks of
+    // the concatenated, padded input: sources A and B are multiples of 32 channels, so a pair never
+    // straddles them)
+    for (int i = 0; i < kNumMfmaConvs; ++i) {
+        const ConvLayer& L = plan.conv[i];
+        if (!L.w3_off) continue;
+        const int cin_real = L.ca_real + L.cb_real;
+        const float* blk = params + L.p_off;
+        Folded f = fold_bn(blk, L.cout_real, cin_real);
+        const int npairs = (L.ca + L.cb) / 32, nct = L.cout / 16;
+        for (int pr = 0; pr < npairs; ++pr)
+            for (int t = 0; t < 27; ++t)
+                for (int ct = 0; ct < nct; ++ct)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int co = 16 * ct + (lane & 15);
+                        const size_t frag = (((size_t)pr * 27 + t) * nct + ct) * 64 + lane;
+                        for (int j = 0; j < 8; ++j) {
+                            const int pc = 32 * pr + 16 * (lane >> 5) + 8 * ((lane >> 4) & 1) + j;
+                            int ci = -1;
+                            if (pc < L.ca) {
+                                if (pc < L.ca_real) ci = pc;
+                            } else {
+                                const int q = pc - L.ca;
+                                if (q < L.cb_real) ci = L.ca_real + q;
+                            }
+                            float v = 0.f;
+                            if (ci >= 0 && co < L.cout_real)
+                                v = (float)((double)blk[((size_t)co * cin_real + ci) * 27 + t] * f.scale[co]);
+                            const uint16_t hbits = plan.dtype == EXASPIM_DT_BF16 ? f32_to_bf16_rne(v)
+                                                                                  : f32_to_f16_rne(v);
+                            std::memcpy(out + L.w3_off + (frag * 8 + j) * 2, &hbits, 2);
                         }
                     }
     }

@@ -633,9 +633,12 @@ def test_predict_rejects_what_float32_cannot_carry(dev):
         inference.predict((vol % 251).astype(np.uint8), model, brightness_clip=1000, **kw)
 
 
-def test_paired_tap_kernel_variant_matches_the_reference(dev, golden):
+@pytest.mark.parametrize("switch", ["EXASPIM_ZPAIR", "EXASPIM_T16"])
+def test_opt_in_kernel_variants_match_the_reference(dev, golden, switch):
     """EXASPIM_ZPAIR=1 runs the 32-cout-slice layers on conv3x3x3_zpair (v_mfma_f32_16x16x32,
-    pairs of taps per instruction, paired weight fragments of plan.cpp): the switch is read once
+    pairs of taps per instruction, paired weight fragments of plan.cpp); EXASPIM_T16=1 runs the
+    64-cout layers of level 1 on conv3x3x3_t16 (v_mfma_f32_16x16x32 over pairs of channel
+    chunks, persistent workgroups, LDS-DMA, K = 32 weight fragments). The switches are read once
     per process, so the check runs in a child process -- default-config 160^3 predict in fp16
     against the reference's golden output, same 1e-3 bar."""
     import os
@@ -655,11 +658,11 @@ m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
 m.to("cuda:0").eval()
 got = inference.predict(synthetic.synth_volume((160, 160, 160), seed=0), m, batch_size=8, verbose=False)
 err = np.abs(got[:, ::5, ::5, ::5] - g["pred_sub"])
-print("zpair fp16 max %%.3e mean %%.3e" %% (err.max(), err.mean()))
+print("variant fp16 max %%.3e mean %%.3e" %% (err.max(), err.mean()))
 assert err.max() < 1e-3
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
        os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g6_default_160.npz"))
-    env = dict(os.environ, EXASPIM_ZPAIR="1")
+    env = dict(os.environ, **{switch: "1"})
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     print(out.stdout[-400:], out.stderr[-400:])
     assert out.returncode == 0

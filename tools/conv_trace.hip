@@ -67,6 +67,13 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(w2_dev, h.data(), w2bytes < h.size() * 2 ? w2bytes : h.size() * 2, hipMemcpyHostToDevice));
         a.weights_paired = w2_dev;
     }
+    void* w3_dev = nullptr;   // K = 32 fragments for conv3x3x3_t16 (timing only: random bits)
+    if (cout % 64 == 0 && cin % 32 == 0) {
+        const size_t w3bytes = (size_t)27 * cin * cout * 2;
+        CK(hipMalloc(&w3_dev, w3bytes));
+        CK(hipMemcpy(w3_dev, h.data(), w3bytes < h.size() * 2 ? w3bytes : h.size() * 2, hipMemcpyHostToDevice));
+        a.weights_k32 = w3_dev;
+    }
     a.dst = dst; a.cout = cout; a.n = n; a.d = a.h = a.w = edge; a.slope = 0.01f;
     if (exaspim::g_variant != 0) {   // the variant must reproduce the library kernel bit for bit
         const int v = exaspim::g_variant;
