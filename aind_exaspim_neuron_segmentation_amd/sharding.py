@@ -171,6 +171,10 @@ def _needs_host_staging(tensor, group):
     return tensor.is_cuda and dist.get_backend(group) == "gloo"
 
 
+_RCCL_DTYPES = (torch.float32, torch.float64, torch.float16, torch.bfloat16, torch.int8,
+                torch.uint8, torch.int32, torch.int64)
+
+
 def _p2p(ops, group):
     """Runs a batch of (kind, tensor, peer) point-to-point transfers."""
     import torch.distributed as dist
@@ -178,6 +182,7 @@ def _p2p(ops, group):
     if not ops:
         return
     staged, reqs = [], []
+    bytewise = dist.get_backend(group) == "nccl"
     for kind, tensor, peer in ops:
         buf = tensor
         if _needs_host_staging(tensor, group):
@@ -185,6 +190,10 @@ def _p2p(ops, group):
                 tensor.shape, dtype=tensor.dtype, device="cpu")
             if kind == "recv":
                 staged.append((tensor, buf))
+        elif bytewise and tensor.dtype not in _RCCL_DTYPES:
+            # RCCL has no 16-bit integer type (the voxels of an input halo): a copy is a
+            # copy, the same memory travels as bytes
+            buf = tensor.view(torch.uint8)
         reqs.append(dist.P2POp(dist.isend if kind == "send" else dist.irecv, buf, peer, group))
     for req in dist.batch_isend_irecv(reqs):
         req.wait()

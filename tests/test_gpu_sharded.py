@@ -129,3 +129,48 @@ def test_bench_launches_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--size", "16"],   # no patch fits: Shard raises in every rank
                          env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert bad.returncode != 0
+
+
+def test_rccl_transport_rehearsal_on_one_rank():
+    """The RCCL ("nccl") transport cannot run between ranks on a one-GPU box (RCCL refuses two
+    ranks on one device), so what can be rehearsed is rehearsed at world size 1 in a child
+    process: group creation the way bench.py does it, the histogram all-reduce on a device int64
+    tensor, the barrier, and sharding._p2p's send/recv pair (to itself, inside one RCCL group
+    call) with the tensors the two exchanges move: float32 partial sums and 16-bit voxels,
+    which RCCL has no type for and which therefore travel as bytes."""
+    import subprocess
+    import sys
+
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import os, sys, torch
+import torch.distributed as dist
+sys.path.insert(0, %r)
+from aind_exaspim_neuron_segmentation_amd import sharding
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)
+g = dist.group.WORLD
+h = torch.arange(65536, dtype=torch.int64, device=dev)
+sharding.all_reduce_sum(h, g)
+assert torch.equal(h.cpu(), torch.arange(65536))
+dist.barrier()
+for dtype in (torch.float32, torch.int16):
+    a = (torch.arange(3 * 5 * 7, device=dev) - 50).to(dtype).reshape(3, 5, 7)
+    b = torch.zeros_like(a)
+    sharding._p2p([("send", a, 0), ("recv", b, 0)], g)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b), dtype
+t = torch.tensor([1.5, 2.5], dtype=torch.float64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert t.tolist() == [1.5, 2.5]
+dist.destroy_process_group()
+print("rccl world-1 rehearsal ok")
+""" % root
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    print(out.stdout[-600:], out.stderr[-1500:])
+    assert out.returncode == 0 and "rehearsal ok" in out.stdout
