@@ -91,6 +91,7 @@ SIGNATURES = {
     "exaspim_stitch_accumulate": (_i32, [_vp, _vp, _i32, _i32, ctypes.POINTER(Window), _vp,
                                          ctypes.POINTER(Block), _vp]),
     "exaspim_stitch_finalize": (_i32, [_vp, _i32, ctypes.POINTER(Window), ctypes.POINTER(Block), _vp]),
+    "exaspim_export_f16": (_i32, [_vp, _vp, ctypes.c_size_t, _vp]),
     "exaspim_synth_volume_u16": (_i32, [_vp, ctypes.POINTER(Block), ctypes.c_uint64, _vp]),
 }
 

@@ -325,6 +325,28 @@ __global__ __launch_bounds__(256) void finalize_kernel(float* __restrict__ accum
     }
 }
 
+// float32 -> IEEE half, round to nearest even (what numpy's astype(float16) does), eight
+// values per thread: 32 B in, 16 B out
+__global__ __launch_bounds__(256) void export_f16_kernel(const float* __restrict__ src,
+                                                        unsigned short* __restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t n8 = n / 8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        const float4 a = reinterpret_cast<const float4*>(src)[2 * i];
+        const float4 b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        unsigned u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            u[k] = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)v[2 * k]) |
+                   ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)v[2 * k + 1]) << 16);
+        reinterpret_cast<uint4*>(dst)[i] = make_uint4(u[0], u[1], u[2], u[3]);
+    }
+    // the last n % 8 values
+    const size_t t = n8 * 8 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) dst[t] = __builtin_bit_cast(unsigned short, (_Float16)src[t]);
+}
+
 static inline unsigned stream_grid(size_t items) {
     const size_t blocks = (items + 255) / 256;
     return (unsigned)(blocks < 8192 ? (blocks ? blocks : 1) : 8192);
@@ -474,6 +496,17 @@ extern "C" int exaspim_stitch_finalize(float* accum_dev, int32_t channels,
     EXA_CHECK_ARG(blk->dims[0] <= 65535 && blk->dims[1] <= 65535, "finalize: block too large");
     const dim3 grid((blk->dims[2] + 255) / 256, blk->dims[1], blk->dims[0]);
     finalize_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(accum_dev, channels, *win, *blk);
+    EXA_CHECK_HIP(hipGetLastError());
+    return EXASPIM_OK;
+}
+
+extern "C" int exaspim_export_f16(const float* src_dev, void* dst_dev, size_t n, void* stream) {
+    EXA_CHECK_ARG(src_dev && dst_dev, "export_f16: NULL buffer");
+    EXA_CHECK_ARG(((uintptr_t)src_dev & 15) == 0 && ((uintptr_t)dst_dev & 15) == 0,
+                  "export_f16: buffers must be 16-byte aligned");
+    if (n == 0) return EXASPIM_OK;
+    export_f16_kernel<<<stream_grid(n / 8 + 8), 256, 0, (hipStream_t)stream>>>(
+        src_dev, static_cast<unsigned short*>(dst_dev), n);
     EXA_CHECK_HIP(hipGetLastError());
     return EXASPIM_OK;
 }

@@ -201,6 +201,14 @@ int exaspim_stitch_finalize(float* accum_dev, int32_t channels,
                             const exaspim_window* win, const exaspim_block* blk,
                             void* stream);
 
+/* dst[i] = (IEEE half) src[i], round to nearest even, for i < n: the reduced-precision
+ * export of a finalised result. The consumer of predict()'s output,
+ * affinities_to_segmentation, starts with affinities.astype(np.float32)
+ * (inference.py:223), so it takes a float16 array as it is; values are in [0, 1], the
+ * rounding error is at most 2.4e-4. src_dev float32, dst_dev 16-bit, both 16-byte
+ * aligned. */
+int exaspim_export_f16(const float* src_dev, void* dst_dev, size_t n, void* stream);
+
 /* ---- synthetic input for benchmarks and tests --------------------------- */
 
 /* vol[z,y,x] = splitmix64(seed + global linear index) % 2000 as uint16. */

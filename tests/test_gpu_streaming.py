@@ -158,3 +158,43 @@ def test_streaming_device_footprint_does_not_grow_with_depth(dev):
     print(f"peak device bytes above baseline: depth 264 -> {shallow}, depth 1056 -> {deep}")
     assert deep <= shallow + (1 << 20)
     assert deep < 3 * 1056 * 96 * 96 * 4 // 2
+
+
+def test_half_precision_export(dev):
+    """out_dtype=numpy.float16 (the reduced-precision export): the finished
+    result rounded to IEEE half on the device -- bit for bit numpy's astype(float16) of the
+    float32 result -- on the host path (slabs), through a write_block sink, and on the
+    device-resident path; the consumer's astype(float32) (inference.py:223) is then within
+    2.4e-4 of the float32 result."""
+    from aind_exaspim_neuron_segmentation_amd import inference
+
+    model = make_model(dev)
+    vol = synthetic.synth_volume((72, 56, 43), seed=12)        # odd row length: unaligned tails
+    kw = dict(patch_shape=(32, 32, 32), overlap=(8, 8, 8), trim=4, batch_size=5)
+    want32 = resident(vol, model, **kw)
+    want16 = want32.astype(np.float16)
+    got = inference.predict(vol, model, verbose=False, out_dtype=np.float16, **kw)
+    assert got.dtype == np.float16 and got.shape == want32.shape
+    np.testing.assert_array_equal(got.view(np.uint16), want16.view(np.uint16))
+    assert np.abs(got.astype(np.float32) - want32).max() <= 2.4415e-4
+    blocks = []
+    inference.predict_streaming(vol, model, verbose=False, out_dtype="float16",
+                                write_block=lambda z0, z1, b: blocks.append(b.copy()), **kw)
+    assert all(b.dtype == np.float16 for b in blocks)
+    np.testing.assert_array_equal(np.concatenate(blocks, axis=1).view(np.uint16), want16.view(np.uint16))
+    t = inference.predict(vol, model, verbose=False, return_device_tensor=True, out_dtype=np.float16, **kw)
+    assert t.dtype == torch.float16 and t.is_cuda
+    np.testing.assert_array_equal(t.cpu().numpy().view(np.uint16), want16.view(np.uint16))
+    # foreground mode: one channel, 3-D result
+    m1 = make_model(dev, out_channels=1, seed=4)
+    f32 = inference.predict(vol, m1, affinity_mode=False, verbose=False, **kw)
+    f16 = inference.predict(vol, m1, affinity_mode=False, verbose=False, out_dtype=np.float16, **kw)
+    assert f16.shape == vol.shape
+    np.testing.assert_array_equal(f16.view(np.uint16), f32.astype(np.float16).view(np.uint16))
+    with pytest.raises(TypeError):
+        inference.predict(vol, model, verbose=False, out_dtype=np.uint8, **kw)
+    # the export entry point on its own: every length class of the 8-wide kernel
+    for n in (1, 7, 8, 9, 4099):
+        src = torch.rand(n + 4, device=dev)[:n].contiguous()
+        out = inference.export_half(src)
+        assert torch.equal(out, src.to(torch.float16))

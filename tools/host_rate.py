@@ -27,7 +27,12 @@ for it in range(3):
     t0 = time.perf_counter()
     out2 = inference.predict_streaming(vol, m, verbose=False, copy_threads=threads)
     t_host2 = time.perf_counter() - t0
+    del out2
+    t0 = time.perf_counter()
+    out2 = inference.predict_streaming(vol, m, verbose=False, copy_threads=threads, out_dtype=np.float16)
+    t_half = time.perf_counter() - t0
     print(f"{edge}^3 {cdt}: device-resident {t_dev:.3f} s ({edge**3/t_dev:.3e} vox/s) | host->host "
           f"{t_host2:.3f} s ({edge**3/t_host2:.3e} vox/s) | instrumented {t_host:.3f} s: "
-          + ", ".join(f"{k} {v:.3f}" for k, v in tm.items()), flush=True)
+          + ", ".join(f"{k} {v:.3f}" for k, v in tm.items())
+          + f" | host->host float16 export {t_half:.3f} s", flush=True)
     del out, out2
