@@ -174,3 +174,81 @@ print("rccl world-1 rehearsal ok")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     print(out.stdout[-600:], out.stderr[-1500:])
     assert out.returncode == 0 and "rehearsal ok" in out.stdout
+
+
+def test_rank_block_of_the_8_gpu_workload_indexes_beyond_2_31():
+    """One rank's share of BASELINE configs[4] (4096 x 2048 x 2048 over a 4 x 2 rank grid), run
+    here without its neighbours: the input block of an interior rank is 1056 x 1056 x 2048 =
+    2.28e9 voxels and its accumulators 6.9e9 floats, i.e. every voxel index of the gather,
+    stitch and finalise kernels passes 2^31 -- sizes no other test reaches. The partial sums
+    at the far corner of the block (largest indices) must equal, bit for bit, those of the
+    same twelve patches run on a small block cut out of the same global volume."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from aind_exaspim_neuron_segmentation_amd import _native, inference, sharding
+    from aind_exaspim_neuron_segmentation_amd.machine_learning.unet3d import UNet3D
+
+    dev = torch.device("cuda:0")
+    if torch.cuda.mem_get_info(dev)[0] < 60 * 2**30:
+        pytest.skip("needs 60 GB of free device memory")
+    sd = synthetic.synth_state_dict(3, 1, seed=1)
+    model = UNet3D(output_channels=3, compute_dtype="fp16")
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    model.to(dev).eval()
+    gshape = (4096, 2048, 2048)
+    plan = inference.SlidingWindow(gshape, (96, 96, 96), (32, 32, 32), 8)
+    shard = sharding.Shard(plan, sharding.rank_grid(8), 2)          # interior along z, first along y
+    assert int(np.prod(shard.input_dims, dtype=np.int64)) > 2**31 and shard.input_origin[0] > 0
+    assert len(shard.starts) == 8192
+
+    def block_volume(origin, dims):
+        t = torch.empty(dims, dtype=torch.int16, device=dev)
+        blk = _native.Block.make(dims, origin, gshape)
+        _native.check(_native.lib().exaspim_synth_volume_u16(t.data_ptr(), blk, 0, None), "synth")
+        return inference.DeviceVolume(t, np.uint16, origin, gshape), blk
+
+    mn, mx = 19.0, 1000.0
+    volume, blk = block_volume(shard.input_origin, shard.input_dims)
+    big = inference.run_sliding_window(volume, model, plan, 3, 16, 1000, mn, mx,
+                                       starts=shard.starts, accum_block=blk)
+    torch.cuda.synchronize()
+    # the last two z and y starts and the last three x starts of the rank
+    zs = sorted({s[0] for s in shard.starts})[-2:]
+    ys = sorted({s[1] for s in shard.starts})[-2:]
+    xs = sorted({s[2] for s in shard.starts})[-3:]
+    sub = [(z, y, x) for z in zs for y in ys for x in xs]
+    lo = (zs[0], ys[0], xs[0])
+    hi = tuple(min(s[-1] + 96, g) for s, g in zip((zs, ys, xs), gshape))
+    dims = tuple(h - l for l, h in zip(lo, hi))
+    svol, sblk = block_volume(lo, dims)
+    small = inference.run_sliding_window(svol, model, plan, 3, 16, 1000, mn, mx, starts=sub,
+                                         accum_block=sblk)
+    # voxels only these twelve patches write: 24 past the first start of the subset on every
+    # axis (the previous patch's trimmed output ends at start - 64 + 88)
+    pure_lo = tuple(l + 24 for l in lo)
+    a = big[(slice(None),) + shard.local(pure_lo, hi, shard.accum_origin)]
+    b = small[(slice(None),) + shard.local(pure_lo, hi, lo)]
+    assert a.shape == b.shape and a.numel() > 0
+    assert bool((b != 0).any())
+    assert torch.equal(a, b)
+    # and the low corner (smallest indices), against its own small block
+    zs, ys, xs = (sorted({s[i] for s in shard.starts})[:2] for i in range(3))
+    sub = [(z, y, x) for z in zs for y in ys for x in xs]
+    lo = (zs[0], ys[0], xs[0])
+    dims = (zs[-1] + 96 - lo[0], ys[-1] + 96 - lo[1], xs[-1] + 96 - lo[2])
+    svol, sblk = block_volume(lo, dims)
+    small = inference.run_sliding_window(svol, model, plan, 3, 16, 1000, mn, mx, starts=sub,
+                                         accum_block=sblk)
+    # up to where the third patch along an axis starts writing (start + 128 + 8)
+    pure_hi = tuple(l + 136 for l in lo)
+    a = big[(slice(None),) + shard.local(lo, pure_hi, shard.accum_origin)]
+    b = small[(slice(None),) + shard.local(lo, pure_hi, lo)]
+    assert torch.equal(a, b) and bool((b != 0).any())
+    # percentiles over 2.28e9 voxels (64-bit counts) and the final division at these sizes
+    p1, p999 = inference.volume_percentiles(volume, 1000, (1, 99.9))
+    assert 18.0 <= p1 <= 21.0 and p999 == 1000.0
+    inference.stitch_finalize(big, plan, blk)
+    inference.stitch_finalize(small, plan, sblk)
+    a = big[(slice(None),) + shard.local(lo, pure_hi, shard.accum_origin)]
+    assert torch.equal(a, small[(slice(None),) + shard.local(lo, pure_hi, lo)])
+    assert float(a.max()) <= 1.0 and float(a[:, 8:, 8:, 8:].min()) > 0.0
