@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define EXASPIM_ABI_VERSION 2
+/* 3: exaspim_export_f16 added (entry points are only ever added within a major line) */
+#define EXASPIM_ABI_VERSION 3
 
 /* error codes */
 #define EXASPIM_OK 0
