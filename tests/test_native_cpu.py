@@ -308,3 +308,38 @@ def test_dtype_rules_and_fractional_clip_percentiles_on_the_host():
         c, vdt = inf._effective_clip(vol.dtype, clip)
         got = inf._percentiles_from_histograms(lambda *a: hist, vol.dtype, (1, 99.9), vdt, c)
         np.testing.assert_array_equal(np.array(got), np.percentile(np.minimum(vol, clip), (1, 99.9)))
+
+
+def test_sliding_window_raises_where_the_reference_stitch_loop_raises():
+    """inference.py:101-116 places a trimmed patch with accum[s:e] += patch[:e - s],
+    s = start + trim, e = min(s + out, dim). A last start with s > dim makes e - s negative:
+    patch[:e - s] is non-empty while accum[s:e] is empty and numpy raises ValueError
+    (possible only if trim > overlap + 1). SlidingWindow raises for exactly those geometries:
+    checked against the slice arithmetic itself on 5000 random axes."""
+    from aind_exaspim_neuron_segmentation_amd import inference
+
+    rng = np.random.default_rng(0)
+    n_raise = 0
+    for _ in range(5000):
+        p = int(rng.integers(4, 40))
+        ov = int(rng.integers(0, p))
+        trim = int(rng.integers(0, (p - 1) // 2 + 1))
+        d = int(rng.integers(1, 120))
+        if 2 * trim >= p:
+            continue
+        out = p - 2 * trim
+        ref_raises = False
+        for s0 in range(0, d - p + (p - ov), p - ov):
+            s = max(s0 + trim, 0)
+            e = min(s + out, d)
+            ref_raises |= len(range(*slice(s, e).indices(d))) != len(range(*slice(0, e - s).indices(out)))
+        try:
+            inference.SlidingWindow((d, d, d), (p, p, p), (ov, ov, ov), trim)
+            ours = False
+        except ValueError as exc:
+            ours = "broadcast" in str(exc)
+        assert ours == ref_raises, (p, ov, trim, d)
+        n_raise += ref_raises
+    assert n_raise > 50
+    # the reference's defaults are far from it
+    inference.SlidingWindow((1024, 1024, 1024), (96, 96, 96), (32, 32, 32), 8)
