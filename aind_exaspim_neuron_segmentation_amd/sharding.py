@@ -123,14 +123,20 @@ class Shard:
             nxt = g[a] if is_last else axis_starts[a][hi_i]
             core_lo.append(0 if is_first else first[a])
             core_hi.append(nxt)
-            own_lo.append(0 if is_first else first[a] + trim)
-            own_hi.append(g[a] if is_last else nxt + trim)
+            # (a last start within "trim" of the end of the volume writes nothing: clip)
+            own_lo.append(0 if is_first else min(first[a] + trim, g[a]))
+            own_hi.append(g[a] if is_last else min(nxt + trim, g[a]))
         self.core_origin = tuple(core_lo)
         self.core_dims = tuple(h - l for l, h in zip(core_lo, core_hi))
         self.own_lo, self.own_hi = tuple(own_lo), tuple(own_hi)
-        # accumulator block = input block (covers every write of my patches)
+        # accumulator block = input block (covers every write of my patches); with an overlap
+        # smaller than the trim the trimmed outputs of neighbouring patches leave gaps that
+        # stay 0, and the gap at a rank face belongs to the owned region: stretch the block
+        # over it
         self.accum_origin = self.input_origin
-        self.accum_dims = self.input_dims
+        self.accum_dims = tuple(
+            max(o + d, h) - o for o, d, h in zip(self.input_origin, self.input_dims, self.own_hi)
+        )
 
     # ---- neighbours -----------------------------------------------------------
     def neighbour(self, dz, dy):
