@@ -95,3 +95,108 @@ def test_predict_geometry_fuzz_vs_oracle(case):
                                 dtype=vol.dtype, keep_input_resident=False,
                                 write_block=lambda z0, z1, b: blocks.append(b.copy()), **kw)
     np.testing.assert_array_equal(np.concatenate(blocks, axis=1 if case["affinity"] else 0), got)
+
+
+def _shard_cases(n, seed):
+    from aind_exaspim_neuron_segmentation_amd import sharding
+
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        patch = tuple(int(16 * rng.integers(1, 3)) for _ in range(3))               # 16, 32
+        overlap = tuple(int(rng.integers(0, p // 2 + 1)) for p in patch)
+        trim = int(rng.integers(0, min(patch) // 4 + 1))
+        world = int(rng.choice([2, 4, 8]))
+        gz, gy = sharding.rank_grid(world)
+        shape = []
+        for axis, (p, o) in enumerate(zip(patch, overlap)):
+            nstarts = (gz, gy, 1)[axis] + int(rng.integers(0, 3))
+            shape.append(o + (p - o) * nstarts - int(rng.integers(0, p - o)))
+        out.append(dict(shape=tuple(shape), patch=patch, overlap=overlap, trim=trim, world=world,
+                        batch=int(rng.integers(1, 10)), seed=300 + i))
+    return out
+
+
+@pytest.mark.parametrize("case", _shard_cases(int(os.environ.get("EXASPIM_FUZZ_SHARD_CASES", "16")),
+                                              seed=int(os.environ.get("EXASPIM_FUZZ_SEED", "5"))),
+                         ids=lambda c: f"w{c['world']}-" + "x".join(map(str, c["shape"])))
+def test_sharded_predict_geometry_fuzz(case, monkeypatch):
+    """Random rank-grid geometries on the device: every rank's block (its own origin inside the
+    global volume, halo included) goes through the gather / U-Net / stitch kernels one rank
+    after the other, the real band exchange then runs with the ranks as threads (mailboxes
+    instead of a process group), and the assembled result must equal the single-process
+    predict(): same zero mask, sums associated differently at rank faces (<= 2e-6)."""
+    import queue
+    import threading
+
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from aind_exaspim_neuron_segmentation_amd import _native, inference, sharding
+    from aind_exaspim_neuron_segmentation_amd.machine_learning.unet3d import UNet3D
+
+    dev = torch.device("cuda:0")
+    try:
+        plan = inference.SlidingWindow(case["shape"], case["patch"], case["overlap"], case["trim"])
+        shards = [sharding.Shard(plan, sharding.rank_grid(case["world"]), r) for r in range(case["world"])]
+    except ValueError as exc:
+        assert any(k in str(exc) for k in ("broadcast", "cannot be split", "overlap band"))
+        return
+    print(case)
+    sd = synthetic.synth_state_dict(3, 0.25, seed=9)
+    model = UNet3D(output_channels=3, width_multiplier=0.25)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    model.to(dev).eval()
+    gvol = synthetic.synth_volume(case["shape"], seed=case["seed"])
+    kw = dict(batch_size=case["batch"], patch_shape=case["patch"], overlap=case["overlap"], trim=case["trim"])
+    want = inference.predict(gvol, model, verbose=False, return_device_tensor=True, **kw)
+    whole = inference.DeviceVolume.from_array(gvol, dev)
+    mn, mx = inference.volume_percentiles(whole, 1000, (1, 99.9))
+    accums = []
+    for sh in shards:
+        in_sl = tuple(slice(o, o + d) for o, d in zip(sh.input_origin, sh.input_dims))
+        block = torch.from_numpy(np.ascontiguousarray(gvol[in_sl]).view(np.int16)).to(dev)
+        volume = inference.DeviceVolume(block, np.uint16, sh.input_origin, plan.shape)
+        blk = _native.Block.make(sh.accum_dims, sh.accum_origin, plan.shape)
+        accums.append(inference.run_sliding_window(volume, model, plan, 3, case["batch"], 1000, mn, mx,
+                                                   starts=sh.starts, accum_block=blk))
+    torch.cuda.synchronize()
+
+    mail = {(a, b): queue.Queue() for a in range(case["world"]) for b in range(case["world"])}
+
+    class Group:
+        def __init__(self, rank):
+            self.rank = rank
+
+    def mailbox_p2p(ops, group):
+        for kind, tensor, peer in ops:
+            if kind == "send":
+                mail[(group.rank, peer)].put(tensor.clone())
+        for kind, tensor, peer in ops:
+            if kind == "recv":
+                tensor.copy_(mail[(peer, group.rank)].get(timeout=60))
+
+    monkeypatch.setattr(sharding, "_p2p", mailbox_p2p)
+    errors = []
+
+    def exchange(rank):
+        try:
+            with torch.cuda.device(dev):
+                sharding.exchange_output_bands(accums[rank], shards[rank], Group(rank))
+                torch.cuda.synchronize()
+        except Exception as exc:        # noqa: BLE001 - reported by the main thread
+            errors.append(f"rank {rank}: {type(exc).__name__}: {exc}")
+
+    threads = [threading.Thread(target=exchange, args=(r,)) for r in range(case["world"])]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors[:2]
+    full = torch.full_like(want, float("nan"))
+    for sh, accum in zip(shards, accums):
+        inference.stitch_finalize(accum, plan, _native.Block.make(sh.accum_dims, sh.accum_origin, plan.shape))
+        own_sl = (slice(None),) + tuple(slice(a, b) for a, b in zip(sh.own_lo, sh.own_hi))
+        full[own_sl] = sharding.owned_result(accum, sh)
+    assert not bool(torch.isnan(full).any())
+    assert torch.equal(full == 0, want == 0)
+    assert float((full - want).abs().max()) <= 2e-6
