@@ -200,3 +200,50 @@ def test_sharded_predict_geometry_fuzz(case, monkeypatch):
     assert not bool(torch.isnan(full).any())
     assert torch.equal(full == 0, want == 0)
     assert float((full - want).abs().max()) <= 2e-6
+
+
+def _net_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        wm = [0.125, 0.25, 0.5, 0.75, 1, 1.5][int(rng.integers(0, 6))]
+        big = wm >= 1
+        shape = tuple(int(16 * rng.integers(1, 3 if big else 5)) for _ in range(3))      # 16 .. 32 / 64
+        out.append(dict(wm=wm, shape=shape, n=int(rng.integers(1, 4 if big else 6)),
+                        oc=int(rng.integers(1, 5)), trilinear=bool(rng.integers(0, 3)),
+                        cdt=["fp32", "fp32", "fp16", "bf16"][int(rng.integers(0, 4))], seed=500 + i))
+    return out
+
+
+@pytest.mark.parametrize("case", _net_cases(int(os.environ.get("EXASPIM_FUZZ_NET_CASES", "20")),
+                                            seed=int(os.environ.get("EXASPIM_FUZZ_SEED", "3"))),
+                         ids=lambda c: f"wm{c['wm']}-{c['cdt']}-" + "x".join(map(str, c["shape"])))
+def test_network_forward_fuzz(case):
+    """Random widths (channel counts from 4 to 768: every cout-slice / tile / split-K choice of
+    the launchers), patch shapes, batch sizes, head widths, both up-block variants and the three
+    compute dtypes against the oracle's float32 network: logits within 1e-4 in fp32,
+    probabilities within 1e-3 (fp16) / 4e-3 (bf16)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from oracle import reference_path as oracle
+
+    from aind_exaspim_neuron_segmentation_amd.machine_learning.unet3d import UNet3D
+
+    dev = torch.device("cuda:0")
+    print(case)
+    sd = synthetic.synth_state_dict(case["oc"], case["wm"], seed=case["seed"], trilinear=case["trilinear"])
+    model = UNet3D(output_channels=case["oc"], width_multiplier=case["wm"], trilinear=case["trilinear"],
+                   compute_dtype=case["cdt"])
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    model.to(dev).eval()
+    rng = np.random.default_rng(case["seed"])
+    x = torch.from_numpy(rng.random((case["n"], 1) + case["shape"], dtype=np.float32))
+    want = oracle.unet_forward(x, oracle.OracleModel(sd).sd)
+    if case["cdt"] == "fp32":
+        got = model(x.to(dev)).cpu()
+        err = float((got - want).abs().max())
+        assert err < 1e-4, err
+    else:
+        got = model.run(x.to(dev), apply_sigmoid=True).cpu()
+        err = float((got - torch.sigmoid(want)).abs().max())
+        assert err < (1e-3 if case["cdt"] == "fp16" else 4e-3), err
