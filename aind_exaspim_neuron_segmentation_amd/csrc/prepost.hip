@@ -70,7 +70,13 @@ template <>
 __device__ __forceinline__ int bin_of<EXASPIM_VOX_F32>(const void* vol, size_t i, double clip,
                                                        int has_clip, int pass, unsigned prefix) {
     float v = static_cast<const float*>(vol)[i];
-    if (has_clip) v = fminf(v, (float)clip);
+    if (has_clip && (double)v > clip) {
+        // a clip float32 cannot hold (float64 images) gets the key of the float32 just above
+        // it, which no voxel can have after clipping: that bin stands for the clip itself
+        float cf = (float)clip;
+        if ((double)cf < clip) cf = __uint_as_float(__float_as_uint(cf) + (cf >= 0.f ? 1u : -1u));
+        v = cf;
+    }
     const unsigned k = f32_key(v);
     if (pass == 0) return (int)(k >> 16);
     return (k >> 16) == prefix ? (int)(k & 0xffffu) : -1;

@@ -163,7 +163,9 @@ int exaspim_unet_timing_read(exaspim_unet* h, double ms_sum[17], int32_t count[1
  * it lands in bin ceil(clip), which then stands for the clip value itself. F32
  * voxels are binned by an order-preserving 32-bit key: pass 0 bins the key's
  * high 16 bits; pass 1 bins the low 16 bits of keys whose high half equals
- * "prefix". Order statistics, and from them numpy's linear-interpolated
+ * "prefix"; voxels above a clip that float32 cannot hold (a float64 image, which
+ * travels as float32) get the key of the float32 just above the clip, which
+ * again stands for the clip value itself. Order statistics, and from them numpy's linear-interpolated
  * percentiles (img_util.py:526), follow exactly from these counts. */
 int exaspim_histogram(const void* vol_dev, int32_t vox_dtype, size_t n,
                       double clip, int32_t has_clip, int32_t pass,

@@ -30,7 +30,7 @@ def _cases(n, seed):
         shape = tuple(int(rng.integers(max(2, o - 3), 2 * p + 25)) for p, o in zip(patch, overlap))
         out.append(dict(
             shape=shape, patch=patch, overlap=overlap, trim=trim, batch=int(rng.integers(1, 10)),
-            affinity=bool(rng.integers(0, 3)), vox=["u16", "u8", "f32", "i16"][int(rng.integers(0, 4))],
+            affinity=bool(rng.integers(0, 3)), vox=["u16", "u8", "f32", "i16", "f64"][int(rng.integers(0, 5))],
             pct=[(1, 99.9), (0, 100), (5, 95)][int(rng.integers(0, 3))], seed=100 + i,
         ))
     return out
@@ -42,6 +42,8 @@ def _volume(case):
         return (v % 251).astype(np.uint8), 200
     if case["vox"] == "f32":
         return v.astype(np.float32) * 0.37 - 3.0, 520.5
+    if case["vox"] == "f64":            # travels as float32; the clip is not a float32 number
+        return v.astype(np.float64) * 0.25 - 11.5, 333.1
     if case["vox"] == "i16":
         return (v.astype(np.int32) - 700).astype(np.int16), 900
     return v, 1000
@@ -249,3 +251,68 @@ def test_network_forward_fuzz(case):
         got = model.run(x.to(dev), apply_sigmoid=True).cpu()
         err = float((got - torch.sigmoid(want)).abs().max())
         assert err < (1e-3 if case["cdt"] == "fp16" else 1e-2), err
+
+
+def _pct_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    kinds = ["u8", "i8", "u16", "i16", "u32", "i32", "i64", "f32", "f64"]
+    out = []
+    for i in range(n):
+        out.append(dict(kind=kinds[int(rng.integers(0, len(kinds)))],
+                        dist=["uniform", "ties", "two", "skew"][int(rng.integers(0, 4))],
+                        size=int(rng.integers(1, 40000)),
+                        pct=tuple(sorted(float(rng.choice([0, 100, rng.uniform(0, 100), float(rng.integers(0, 101))]))
+                                         for _ in range(2))),
+                        clip=[None, "int", "frac", "low", "high"][int(rng.integers(0, 5))], seed=700 + i))
+    return out
+
+
+@pytest.mark.parametrize("case", _pct_cases(int(os.environ.get("EXASPIM_FUZZ_PCT_CASES", "40")),
+                                            seed=int(os.environ.get("EXASPIM_FUZZ_SEED", "9"))),
+                         ids=lambda c: f"{c['kind']}-{c['dist']}-{c['clip']}-{c['size']}")
+def test_percentile_fuzz_vs_numpy(case):
+    """np.percentile(np.minimum(img, clip), pcts) (inference.py:79, img_util.py:524) for random
+    dtypes, value distributions (ties, two-valued, skewed), sizes, percentile pairs (0 and 100
+    included) and clips (none, integer, fractional, below and above the data): the device
+    histogram path must return numpy's two numbers exactly, or raise where numpy / the float32
+    carrier cannot represent the input."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from aind_exaspim_neuron_segmentation_amd import inference
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(case["seed"])
+    dt = {"u8": np.uint8, "i8": np.int8, "u16": np.uint16, "i16": np.int16, "u32": np.uint32,
+          "i32": np.int32, "i64": np.int64, "f32": np.float32, "f64": np.float64}[case["kind"]]
+    n = case["size"]
+    if np.dtype(dt).kind in "ui":
+        info = np.iinfo(dt)
+        lo, hi = max(info.min, -30000), min(info.max, 60000)        # float32-exact range for the wide types
+        base = {"uniform": lambda: rng.integers(lo, hi + 1, n),
+                "ties": lambda: rng.integers(lo, min(lo + 5, hi) + 1, n),
+                "two": lambda: rng.choice([lo, hi], n),
+                "skew": lambda: np.minimum(hi, lo + (rng.exponential(30.0, n)).astype(np.int64))}[case["dist"]]()
+        arr = base.astype(dt)
+    else:
+        base = {"uniform": lambda: rng.uniform(-500, 2000, n), "ties": lambda: rng.integers(0, 4, n) * 0.25,
+                "two": lambda: rng.choice([-1.5, 1234.75], n), "skew": lambda: rng.exponential(50.0, n)}[case["dist"]]()
+        arr = base.astype(np.float32).astype(dt)                     # float64 inputs must be float32-exact
+    arr = arr.reshape(1, 1, -1)
+    span = float(arr.max()) - float(arr.min())
+    clip = {None: None, "int": int(float(arr.min()) + 0.6 * span), "frac": float(arr.min()) + 0.5 * span + 0.25,
+            "low": int(float(arr.min())) - 3, "high": int(float(arr.max())) + 3}[case["clip"]]
+    print(case, "clip", clip)
+    try:
+        ref = np.minimum(arr, clip) if clip is not None else arr
+    except OverflowError:            # numpy refuses the clip for this dtype: so must predict
+        with pytest.raises(OverflowError):
+            inference.volume_percentiles(inference.DeviceVolume.from_array(arr, dev), clip, case["pct"])
+        return
+    want = np.percentile(ref, case["pct"])
+    try:
+        vol = inference.DeviceVolume.from_array(arr, dev)
+        mn, mx = inference.volume_percentiles(vol, clip, case["pct"])
+    except NotImplementedError as exc:   # a fractional clip that float32 cannot hold
+        assert "float32" in str(exc) or "promotes" in str(exc)
+        return
+    assert (float(mn), float(mx)) == (float(want[0]), float(want[1])), (mn, mx, want)
