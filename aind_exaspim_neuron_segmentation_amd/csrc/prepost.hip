@@ -326,7 +326,9 @@ __global__ __launch_bounds__(256) void finalize_kernel(float* __restrict__ accum
     const int cnt = cz * cy * cx;
     if (cnt > 1) {
         const size_t i = ((size_t)z * blk.dims[1] + y) * blk.dims[2] + x;
-        const float wgt = (float)cnt;
+        // the reference counts in float16 (inference.py:92, accum_wgt += 1): 2048 + 1 rounds
+        // back to 2048, so its weights stop there (only strides of a voxel or two get that far)
+        const float wgt = (float)min(cnt, 2048);
         for (int c = 0; c < channels; ++c) accum[c * avox + i] = __fdiv_rn(accum[c * avox + i], wgt);
     }
 }

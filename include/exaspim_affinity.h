@@ -199,7 +199,8 @@ int exaspim_stitch_accumulate(const float* pred_dev, const int32_t* starts_dev,
 
 /* accum[c, v] /= (number of patches whose trimmed output covers v) where that
  * number is non-zero (it is a product of three per-axis counts fixed by the
- * geometry alone); uncovered voxels keep 0. */
+ * geometry alone), capped at 2048 where the reference's float16 weights stop
+ * counting (inference.py:92); uncovered voxels keep 0. */
 int exaspim_stitch_finalize(float* accum_dev, int32_t channels,
                             const exaspim_window* win, const exaspim_block* blk,
                             void* stream);

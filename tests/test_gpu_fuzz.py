@@ -316,3 +316,132 @@ def test_percentile_fuzz_vs_numpy(case):
         assert "float32" in str(exc) or "promotes" in str(exc)
         return
     assert (float(mn), float(mx)) == (float(want[0]), float(want[1])), (mn, mx, want)
+
+
+def _gather_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        patch = tuple(int(rng.integers(1, 41)) for _ in range(3))
+        shape = tuple(int(rng.integers(1, 2 * p + 8)) for p in patch)       # down to 1 voxel: repeated reflection
+        overlap = tuple(int(rng.integers(0, p)) for p in patch)
+        out.append(dict(shape=shape, patch=patch, overlap=overlap,
+                        vox=["u16", "u8", "i16", "f32", "f64", "i32"][int(rng.integers(0, 6))],
+                        clip=[None, "mid", "frac"][int(rng.integers(0, 3))],
+                        block=bool(rng.integers(0, 2)), seed=900 + i))
+    return out
+
+
+@pytest.mark.parametrize("case", _gather_cases(int(os.environ.get("EXASPIM_FUZZ_GATHER_CASES", "40")),
+                                               seed=int(os.environ.get("EXASPIM_FUZZ_SEED", "13"))),
+                         ids=lambda c: f"{c['vox']}-{c['clip']}-" + "x".join(map(str, c["shape"])))
+def test_gather_fuzz_bit_exact_vs_oracle(case):
+    """_get_batch_inputs (inference.py:166-192: slice to the image, numpy 'reflect' padding on
+    the high side -- repeated when the pad exceeds the piece, down to one-voxel axes -- clip,
+    float64 normalisation, float32 cast) for random image / patch shapes, overlaps, voxel dtypes
+    and clips, from the whole volume and from a block with its own origin: bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from oracle import reference_path as oracle
+
+    from aind_exaspim_neuron_segmentation_amd import inference
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(case["seed"])
+    base = rng.integers(0, 3000, case["shape"])
+    arr = {"u16": lambda: base.astype(np.uint16), "u8": lambda: (base % 256).astype(np.uint8),
+           "i16": lambda: (base - 1500).astype(np.int16), "f32": lambda: (base * 0.37 - 40).astype(np.float32),
+           "f64": lambda: (base * 0.25 - 11.5).astype(np.float64),
+           "i32": lambda: (base * 7 - 9000).astype(np.int32)}[case["vox"]]()
+    lo, hi = float(arr.min()), float(arr.max())
+    clip = {None: None, "mid": int(lo + 0.5 * (hi - lo)), "frac": lo + 0.4 * (hi - lo) + 0.3}[case["clip"]]
+    if clip is not None and case["vox"] == "f32":
+        clip = float(np.float32(clip))      # numpy casts a python float to the image's float32
+    print(case, "clip", clip)
+    clipped = np.minimum(arr, clip) if clip is not None else arr
+    mn, mx = np.percentile(clipped, (1, 99.9))
+    img = oracle.normalize(clipped)[None, None]
+    starts = list(oracle.generate_patch_starts(img.shape, case["patch"], case["overlap"]))
+    if not starts:
+        return
+    starts = [starts[i] for i in rng.permutation(len(starts))[:12]]
+    want = oracle.get_batch_inputs(img, starts, case["patch"]).numpy()
+    if case["block"]:
+        # a block covering exactly what these patches read, at its own origin
+        b_lo = tuple(min(s[a] for s in starts) for a in range(3))
+        b_hi = tuple(min(max(s[a] for s in starts) + case["patch"][a], arr.shape[a]) for a in range(3))
+        sub = np.ascontiguousarray(arr[tuple(slice(a, b) for a, b in zip(b_lo, b_hi))])
+        whole = inference.DeviceVolume.from_array(sub, dev)
+        vol = inference.DeviceVolume(whole.tensor, arr.dtype, b_lo, arr.shape, storage_dtype=whole.storage_dtype)
+    else:
+        vol = inference.DeviceVolume.from_array(arr, dev)
+    sdev = torch.tensor(starts, dtype=torch.int32, device=dev)
+    try:
+        got = inference._get_batch_inputs(vol, sdev, case["patch"], dev, clip=clip, mn=mn, mx=mx)
+    except NotImplementedError:
+        return
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def _stitch_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        patch = tuple(int(rng.integers(3, 21)) for _ in range(3))
+        trim = int(rng.integers(0, (min(patch) - 1) // 2 + 1))
+        overlap = tuple(int(rng.integers(0, p)) for p in patch)
+        shape = tuple(int(rng.integers(1, 2 * p + 12)) for p in patch)
+        out.append(dict(shape=shape, patch=patch, overlap=overlap, trim=trim,
+                        channels=int(rng.integers(1, 5)), batch=int(rng.choice([1, 3, 7, 16, 64, 65, 200])),
+                        seed=1100 + i))
+    # the reference keeps its weights in float16 (inference.py:92): counts stop at 2048
+    out.append(dict(shape=(27, 27, 27), patch=(14, 14, 14), overlap=(13, 13, 13), trim=0, channels=1,
+                    batch=128, seed=1099))
+    return out
+
+
+@pytest.mark.parametrize("case", _stitch_cases(int(os.environ.get("EXASPIM_FUZZ_STITCH_CASES", "30")),
+                                               seed=int(os.environ.get("EXASPIM_FUZZ_SEED", "17"))),
+                         ids=lambda c: f"b{c['batch']}-" + "x".join(map(str, c["shape"])))
+def test_stitch_fuzz_bit_exact_vs_reference_loop(case):
+    """The stitch loop and the final divide (inference.py:91-125: float32 sums in patch order,
+    float16 weights, np.divide where the weight is non-zero) restated in numpy, against
+    exaspim_stitch_accumulate / exaspim_stitch_finalize for random geometries, channel counts
+    and batch sizes (including the > 64-patch path): bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from aind_exaspim_neuron_segmentation_amd import inference
+
+    dev = torch.device("cuda:0")
+    shape, patch, trim, channels = case["shape"], case["patch"], case["trim"], case["channels"]
+    try:
+        plan = inference.SlidingWindow(shape, patch, case["overlap"], trim)
+    except ValueError as exc:
+        assert "broadcast" in str(exc)
+        return
+    starts = plan.starts()
+    print(case, len(starts), "patches")
+    rng = np.random.default_rng(case["seed"])
+    preds = rng.random((len(starts), channels) + patch, dtype=np.float32)
+    accum = np.zeros((channels,) + shape, np.float32)
+    wgt = np.zeros(shape, np.float16)
+    for p, s in zip(preds, starts):
+        trimmed = p[..., trim:-trim, trim:-trim, trim:-trim] if trim > 0 else p
+        s0 = [max(si + trim, 0) for si in s]
+        e = [min(a + b, d) for a, b, d in zip(s0, trimmed.shape[1:], shape)]
+        sl = tuple(slice(a, b) for a, b in zip(s0, e))
+        ps = tuple(slice(0, b - a) for a, b in zip(s0, e))
+        accum[(slice(None),) + sl] += trimmed[(slice(None),) + ps]
+        wgt[sl] += 1
+    np.divide(accum, wgt, out=accum, where=wgt != 0)
+
+    block = inference._native.Block.make(shape)
+    acc_dev = torch.zeros((channels,) + shape, dtype=torch.float32, device=dev)
+    if starts:
+        sdev = torch.tensor(starts, dtype=torch.int32, device=dev)
+        pdev = torch.tensor(preds, device=dev)
+        for i in range(0, len(starts), case["batch"]):
+            inference.stitch_accumulate(pdev[i:i + case["batch"]].contiguous(), sdev[i:i + case["batch"]],
+                                        plan, acc_dev, block)
+    inference.stitch_finalize(acc_dev, plan, block)
+    np.testing.assert_array_equal(acc_dev.cpu().numpy(), accum)
