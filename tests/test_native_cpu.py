@@ -343,3 +343,7 @@ def test_sliding_window_raises_where_the_reference_stitch_loop_raises():
     assert n_raise > 50
     # the reference's defaults are far from it
     inference.SlidingWindow((1024, 1024, 1024), (96, 96, 96), (32, 32, 32), 8)
+    # an axis without any patch start: the loop never runs, nothing raises (the result is zeros)
+    with pytest.raises(ValueError, match="broadcast"):
+        inference.SlidingWindow((86, 40, 3), (48, 32, 16), (9, 13, 2), 4)
+    inference.SlidingWindow((86, 12, 3), (48, 32, 16), (9, 13, 2), 4)
