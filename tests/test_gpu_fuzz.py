@@ -447,3 +447,27 @@ def test_stitch_fuzz_bit_exact_vs_reference_loop(case):
                                         plan, acc_dev, block)
     inference.stitch_finalize(acc_dev, plan, block)
     np.testing.assert_array_equal(acc_dev.cpu().numpy(), accum)
+
+
+def test_very_large_batches_of_small_patches():
+    """batch_size is the caller's to choose (inference.py:33): 6000 patches of 16^3 in one batch
+    exceed what one gather / stitch launch takes (65535 grid rows), so the wrappers go in
+    pieces -- same bits as batches of 16."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from aind_exaspim_neuron_segmentation_amd import inference
+    from aind_exaspim_neuron_segmentation_amd.machine_learning.unet3d import UNet3D
+
+    dev = torch.device("cuda:0")
+    sd = synthetic.synth_state_dict(3, 0.25, seed=9)
+    model = UNet3D(output_channels=3, width_multiplier=0.25)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    model.to(dev).eval()
+    vol = synthetic.synth_volume((160, 168, 152), seed=77)
+    kw = dict(patch_shape=(16, 16, 16), overlap=(8, 8, 8), trim=2)
+    assert inference.count_patches((1, 1) + vol.shape, kw["patch_shape"], kw["overlap"]) > 6000
+    small = inference.predict(vol, model, batch_size=16, verbose=False, return_device_tensor=True, **kw)
+    big = inference.predict(vol, model, batch_size=6000, verbose=False, return_device_tensor=True, **kw)
+    assert torch.equal(small, big)
+    host = inference.predict(vol, model, batch_size=6000, verbose=False, **kw)
+    np.testing.assert_array_equal(host, small.cpu().numpy())
