@@ -4,6 +4,7 @@ text/JSON files committed under profiles/.
 
   python profiles/summarize.py stats <kernel_stats.csv> <out.txt>
   python profiles/summarize.py pmc <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [dtype]
+  python profiles/summarize.py util <mfma_counter_collection.csv> <lds_counter_collection.csv> <out.json> [dtype]
 
 HBM traffic per launch follows MI355X_MICROARCH.md section HBM: FETCH_SIZE and
 WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide
@@ -58,8 +59,46 @@ def pmc(fetch_path, write_path, out, dtype):
     json.dump({"dtype": dtype, "kernels": table}, open(out, "w"), indent=1)
 
 
+def util(mfma_path, lds_path, out, dtype):
+    """Matrix-pipe utilisation and LDS bank-conflict share per kernel symbol from two PMC passes:
+    --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE and --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE.
+    MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)."""
+    def agg(path):
+        d = collections.defaultdict(lambda: collections.defaultdict(float))
+        n = collections.defaultdict(set)
+        for r in csv.DictReader(open(path)):
+            k = short(r["Kernel_Name"]).split("(")[0]
+            d[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            n[k].add(r["Dispatch_Id"])
+        return d, n
+
+    m, mn = agg(mfma_path)
+    l, _ = agg(lds_path)
+    table = {}
+    for k in sorted(m):
+        gui = m[k].get("GRBM_GUI_ACTIVE", 0.0)
+        busy = m[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+        if gui <= 0 or busy <= 0:
+            continue
+        idx = l.get(k, {}).get("SQ_LDS_IDX_ACTIVE", 0.0)
+        table[k] = {
+            "launches": len(mn[k]),
+            "mfma_busy_pct_of_simd_cycles": round(100.0 * busy / (gui / 8.0 * 1024.0), 1),
+            "lds_bank_conflict_pct_of_lds_active_cycles":
+                round(100.0 * l[k].get("SQ_LDS_BANK_CONFLICT", 0.0) / idx, 1) if idx > 0 else None,
+        }
+        print(f"{k[:80]:80s} n={len(mn[k]):4d} mfma busy {table[k]['mfma_busy_pct_of_simd_cycles']:5.1f} %  "
+              f"lds conflicts {table[k]['lds_bank_conflict_pct_of_lds_active_cycles']} %")
+    note = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE and --pmc SQ_LDS_BANK_CONFLICT "
+            "SQ_LDS_IDX_ACTIVE (separate passes, --kernel-trace only) over bench.py --size 256 --steps 1 "
+            "--warmup 0; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)")
+    json.dump({"dtype": dtype, "note": note, "kernels": table}, open(out, "w"), indent=1)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "util":
+        util(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else "fp16")
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else "bf16")
