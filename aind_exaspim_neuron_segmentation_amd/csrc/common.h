@@ -143,7 +143,7 @@ struct ConvArgs {
     int org[3] = {0, 0, 0};
     int ext[3] = {0, 0, 0};
     // Optional fused MaxPool3d(2) (unet3d.py:195) of this conv's output, written to
-    // pool_dst as (n, cout, d/2, h/2, w/2) in the same layout (z-column kernel only:
+    // pool_dst as (n, cout, d/2, h/2, w/2) in the same layout (every tile shape but 6^3:
     // ask conv_can_fuse_pool first); saves re-reading the whole skip tensor.
     void* pool_dst = nullptr;
     // Optional scratch for split-K (t14 kernel): launches with too few workgroups to fill
@@ -168,7 +168,7 @@ int launch_conv3x3x3_thin(int dtype, const ConvArgs& a, hipStream_t stream);
 // remainder is 1..4 voxels, else ext itself
 int conv_zcol_main_extent(int ext, int axis);
 bool conv_can_fuse_head(int cout, int w, int head_oc);
-bool conv_can_fuse_pool(int cout, int d, int h, int w);
+bool conv_can_fuse_pool(int dtype, int cout, int d, int h, int w);
 
 // xpad: scratch for the zero-bordered copy of x, n * (d+2)(h+2)(wd+2) floats
 int launch_conv_first(int dtype, const float* x, float* xpad, const float* w, const float* bias,

@@ -51,9 +51,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
-struct F32Tag { static constexpr int kG = 4; };
-struct BF16Tag { static constexpr int kG = 8; };
-struct F16Tag { static constexpr int kG = 8; };
+struct F32Tag { static constexpr int kG = 4; static constexpr int kCode = EXASPIM_DT_F32; };
+struct BF16Tag { static constexpr int kG = 8; static constexpr int kCode = EXASPIM_DT_BF16; };
+struct F16Tag { static constexpr int kG = 8; static constexpr int kCode = EXASPIM_DT_F16; };
 
 template <typename Tag>
 __device__ __forceinline__ void mma(f32x16& acc, const uint4& wf, const uint4& xf);
@@ -217,8 +217,13 @@ __device__ __forceinline__ void store4<F16Tag>(void* dst, size_t off, float a, f
 // one barrier per chunk instead of two. The DMA is issued as inline assembly -- through the
 // builtin hipcc puts a vmcnt(0) wait in front of every later LDS read, because it cannot see
 // that they touch the other buffer -- and waited for explicitly before the chunk's barrier.
+// POOL: the epilogue also writes the layer's MaxPool3d(2) (the input of the next Down block,
+// unet3d.py:194-196) to a.pool_dst: every wave parks all its output groups in LDS, and after one
+// workgroup barrier any thread can take the maximum over a 2 x 2 x 2 block of the tile (planes z
+// and z + 1 belong to different waves). The skip tensor is not read again and the separate
+// max-pool launch disappears. Same bits as maxpool2_kernel: the maximum of stored values.
 template <typename Tag, int TZ, int TY, int TX, int WAVES_M, int WAVES_N, int MT, int NT, int MINW, int PD,
-          bool ZORD = false, bool DMA = false>
+          bool ZORD = false, bool DMA = false, bool POOL = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
     ConvArgs a, int tiles_z, int tiles_y, int tiles_x) {
     constexpr int G = Tag::kG;
@@ -241,9 +246,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
     constexpr int NITEMS = (2 * HVD + NTHREADS - 1) / NTHREADS;
     constexpr int RECB = NT * 32 * ES;              // bytes of one voxel's output slice
     constexpr int RECP = RECB + 16;                 // padded LDS stride (8-way -> 2-way conflicts)
-    constexpr int EPI_UNITS = NWAVES * 32 * RECP / 16;
+    constexpr int EPI_UNITS = NWAVES * (POOL ? MT : 1) * 32 * RECP / 16;   // POOL: all MT groups at once
     constexpr int IMG = 2 * HV;                     // slots of one image (two channel groups)
     constexpr int LDS_UNITS = (DMA ? 2 : 1) * IMG > EPI_UNITS ? (DMA ? 2 : 1) * IMG : EPI_UNITS;
+    static_assert(!POOL || (!DMA && WAVES_M * MT * 32 == TZ * TY * TX && TZ % 2 == 0 && TY % 2 == 0 && TX % 2 == 0),
+                  "pooled tile shape");
     constexpr int NBLK = HV / 64;                   // DMA: 64-slot blocks per plane
     constexpr int NDMA = DMA ? (2 * NBLK + NWAVES - 1) / NWAVES : 1;   // blocks per wave and image
     static_assert(!DMA || HXS == HX, "DMA staging wants dense rows");
@@ -505,7 +512,80 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
     }
 
     // ---- epilogue: bias + LeakyReLU, transposed through LDS ------------------
-    char* wl = reinterpret_cast<char*>(lds) + wave * (32 * RECP);
+    char* wl = reinterpret_cast<char*>(lds) + wave * ((POOL ? MT : 1) * 32 * RECP);
+    if (POOL) {
+        // all groups first: group mt of wave w sits at ((w * MT + mt) * 32 + voxel) * RECP
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cl = nt * 32 + 8 * q + 4 * half;
+                    store4<Tag>(wl + mt * (32 * RECP), (size_t)(r * RECP) / ES + cl,
+                                leaky(acc[mt][nt][4 * q + 0], a.slope), leaky(acc[mt][nt][4 * q + 1], a.slope),
+                                leaky(acc[mt][nt][4 * q + 2], a.slope), leaky(acc[mt][nt][4 * q + 3], a.slope));
+                }
+        __syncthreads();
+        constexpr int NPL = RECB / 32;
+        {   // the layer's own output, as below
+            const int vv = lane >> 1, sub = lane & 1;
+            char* const dplane = static_cast<char*>(a.dst) +
+                                 ((size_t)nb * (a.cout / KC) + ntile0 * (32 / KC)) * patch_vox * 32;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = (wm * MT + mt) * 32 + vv;
+                const int z = m / (TY * TX), y = (m / TX) % TY, x = m % TX;
+                const int gz = z0 + z, gy = y0 + y, gx = x0 + x;
+                const bool ok = gz < zend && gy < yend && gx < xend;
+                const size_t vox = ((size_t)gz * a.h + gy) * a.w + gx;
+#pragma unroll
+                for (int ck = 0; ck < NPL; ++ck) {
+                    const uint4 val = *reinterpret_cast<const uint4*>(
+                        wl + mt * (32 * RECP) + vv * RECP + (ck * 2 + sub) * 16);
+                    if (ok)
+                        *reinterpret_cast<uint4*>(dplane + ((size_t)ck * patch_vox + vox) * 32 + sub * 16) = val;
+                }
+            }
+        }
+        // MaxPool3d(2): piece p = 16-byte group "sub" of pooled voxel (pz, py, px) in chunk plane ck
+        // of cout slice wn; lanes run along (px, sub), so a row of the pooled tile is one run of
+        // TX / 2 x 32 contiguous bytes
+        constexpr int PX = TX / 2, PY = TY / 2, PZ = TZ / 2;
+        constexpr int NPIECE = 2 * PX * PY * PZ * NPL * WAVES_N;
+        const int pd = a.d >> 1, ph = a.h >> 1, pw2 = a.w >> 1;
+        const size_t pvox = (size_t)pd * ph * pw2;
+        const char* const lb = reinterpret_cast<const char*>(lds);
+#pragma unroll
+        for (int p0 = 0; p0 < NPIECE; p0 += NTHREADS) {
+            const int pp = p0 + tid;
+            const int sub = pp & 1, px = (pp >> 1) % PX;
+            int rest = (pp >> 1) / PX;
+            const int py = rest % PY; rest /= PY;
+            const int pz = rest % PZ; rest /= PZ;
+            const int ck = rest % NPL, pwn = rest / NPL;
+            const int qz = (z0 >> 1) + pz, qy = (y0 >> 1) + py, qx = (x0 >> 1) + px;
+            if (pp < NPIECE && qz < pd && qy < ph && qx < pw2) {
+                uint4 mx;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int m = ((2 * pz + (k >> 2)) * TY + 2 * py + ((k >> 1) & 1)) * TX + 2 * px + (k & 1);
+                    const int w_src = (m / (MT * 32)) * WAVES_N + pwn;      // wave that produced it
+                    const uint4 v = *reinterpret_cast<const uint4*>(
+                        lb + (size_t)((w_src * MT + (m / 32) % MT) * 32 + m % 32) * RECP + (ck * 2 + sub) * 16);
+                    if (ES == 2) mx = k == 0 ? key16(v) : maxkey16(mx, key16(v));   // order-preserving keys
+                    else mx = k == 0 ? v : max16<Tag>(mx, v);
+                }
+                if (ES == 2) mx = key16(mx);
+                const int ptile = (blockIdx.y * WAVES_N + pwn) * NT;   // first 32-cout tile of that slice
+                char* const pplane = static_cast<char*>(a.pool_dst) +
+                                     ((size_t)nb * (a.cout / KC) + ptile * (32 / KC) + ck) * pvox * 32;
+                *reinterpret_cast<uint4*>(pplane + (((size_t)qz * ph + qy) * pw2 + qx) * 32 + sub * 16) = mx;
+            }
+        }
+        EXA_TRACE(14);
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -1821,7 +1901,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 template <typename Tag, int TZ, int TY, int TX, int WAVES_M, int WAVES_N, int MT, int NT, int MINW, int PD = 3,
-          bool ZORD = false, bool DMA = false>
+          bool ZORD = false, bool DMA = false, bool POOL = false>
 static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
     constexpr int NWG = WAVES_N * NT * 32;
     if (a.cout % NWG != 0) {
@@ -1848,7 +1928,7 @@ static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
     const int nchunks = (a.ca + a.cb) / (2 * Tag::kG);
     const size_t patch_vox_all = (size_t)a.d * a.h * a.w;
     const size_t nvox_all = (size_t)a.n * patch_vox_all;
-    if (a.partial && whole && !a.head_out && !a.pool_dst && wgs * 2 <= resident_workgroups(2)) {
+    if (a.partial && whole && !a.head_out && wgs * 2 <= resident_workgroups(2)) {
         int ks = (int)(resident_workgroups(2) / wgs);
         if (ks > 4) ks = 4;
         if (ks > nchunks) ks = nchunks;
@@ -1856,19 +1936,42 @@ static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
         b.ksplit = ks;
     }
     dim3 grid((unsigned)blocks, a.cout / NWG, b.ksplit);
-    conv3x3x3_t14<Tag, TZ, TY, TX, WAVES_M, WAVES_N, MT, NT, MINW, PD, ZORD, DMA>
-        <<<grid, WAVES_M * WAVES_N * 64, 0, stream>>>(b, tz, ty, tx);
+    if (POOL && b.ksplit > 1) {
+        // a split layer's output exists only after the reduction: its max-pool stays a launch of
+        // its own (tiny layers; the split is a function of the layer, so is this choice)
+        b.pool_dst = nullptr;
+        conv3x3x3_t14<Tag, TZ, TY, TX, WAVES_M, WAVES_N, MT, NT, MINW, PD, ZORD, DMA, false>
+            <<<grid, WAVES_M * WAVES_N * 64, 0, stream>>>(b, tz, ty, tx);
+    } else {
+        conv3x3x3_t14<Tag, TZ, TY, TX, WAVES_M, WAVES_N, MT, NT, MINW, PD, ZORD, DMA, POOL>
+            <<<grid, WAVES_M * WAVES_N * 64, 0, stream>>>(b, tz, ty, tx);
+    }
     EXA_CHECK_HIP(hipGetLastError());
     if (b.ksplit > 1) {
         const size_t items = nvox_all * (a.cout / 4);
         splitk_reduce_kernel<Tag><<<(unsigned)((items + 255) / 256), 256, 0, stream>>>(
             a.partial, a.bias, a.dst, nvox_all, (size_t)a.d * a.h * a.w, a.cout, b.ksplit, a.slope);
         EXA_CHECK_HIP(hipGetLastError());
+        if (POOL)
+            return launch_maxpool2(Tag::kCode, a.dst, a.pool_dst, a.n, a.d, a.h, a.w, a.cout, stream);
     }
     return EXASPIM_OK;
 }
 
-// 32-cout slice on z-column tiles of TZ planes, with or without the fused head
+template <typename Tag> struct ES_of { static constexpr int value = 16 / Tag::kG; };   // bytes per element
+
+// t14 configuration with or without the fused max-pool
+template <typename Tag, int TZ, int TY, int TX, int WAVES_M, int WAVES_N, int MT, int NT, int MINW>
+static int launch_cfg_pool(const ConvArgs& a, hipStream_t stream) {
+    // (16-bit types only: with float32 records the parked groups of the 64-cout shapes take
+    // 139 KB of LDS and the CU would hold one workgroup; conv_can_fuse_pool says no for those)
+    if constexpr (ES_of<Tag>::value == 2) {
+        if (a.pool_dst)
+            return launch_cfg<Tag, TZ, TY, TX, WAVES_M, WAVES_N, MT, NT, MINW, 3, false, false, true>(a, stream);
+    }
+    return launch_cfg<Tag, TZ, TY, TX, WAVES_M, WAVES_N, MT, NT, MINW>(a, stream);
+}
+
 // 32-cout slice on z-column tiles of TZ planes, with or without the fused head
 template <typename Tag, int TZ, int D>
 static int launch_zpipe_head(const ConvArgs& a, hipStream_t stream) {
@@ -1917,7 +2020,7 @@ static int launch_typed(const ConvArgs& a, hipStream_t stream) {
             static int t16 = -1;
             if (t16 < 0) { const char* e = getenv("EXASPIM_T16"); t16 = e && e[0] == '1'; }
             const bool whole = a.ext[0] == a.d && a.ext[1] == a.h && a.ext[2] == a.w;
-            if (t16 && a.weights_k32 && whole && a.cout == 64 && a.ca % 32 == 0 && a.cb % 32 == 0) {
+            if (t16 && !a.pool_dst && a.weights_k32 && whole && a.cout == 64 && a.ca % 32 == 0 && a.cb % 32 == 0) {
                 const int tz = cdiv(a.d, 4), ty = cdiv(a.h, 8), tx = cdiv(a.w, 16);
                 const int ntiles = tz * ty * tx * a.n;
                 long long nwg = resident_workgroups(1) / 8 * 8;   // one persistent workgroup per CU
@@ -1931,28 +2034,32 @@ static int launch_typed(const ConvArgs& a, hipStream_t stream) {
 #ifndef EXASPIM_T14_DMA
 #define EXASPIM_T14_DMA 0
 #endif
+        if (a.pool_dst) return launch_cfg_pool<Tag, 4, 8, 16, 4, 1, 4, 2, 2>(a, stream);
         return launch_cfg<Tag, 4, 8, 16, 4, 1, 4, 2, 2, 3, false, EXASPIM_T14_DMA != 0>(a, stream);
     }
     if (a.w > 12) {
-        if (a.cout % 64 == 0) return launch_cfg<Tag, 4, 4, 24, 4, 1, 3, 2, 2>(a, stream);
-        return launch_cfg<Tag, 4, 4, 24, 4, 1, 3, 1, 2>(a, stream);
+        if (a.cout % 64 == 0) return launch_cfg_pool<Tag, 4, 4, 24, 4, 1, 3, 2, 2>(a, stream);
+        return launch_cfg_pool<Tag, 4, 4, 24, 4, 1, 3, 1, 2>(a, stream);
     }
     if (a.w > 6) {
         // 256 couts and more: 32-cout slices on two-wave workgroups fill the 256 CUs better
         // than 128-cout slices (144 tiles per batch of 16 at the 12^3 level)
-        if (a.cout % 256 == 0) return launch_cfg<Tag, 4, 4, 12, 2, 1, 3, 1, 2>(a, stream);
-        if (a.cout % 128 == 0) return launch_cfg<Tag, 4, 4, 12, 2, 2, 3, 2, 2>(a, stream);
-        if (a.cout % 64 == 0) return launch_cfg<Tag, 4, 4, 12, 2, 2, 3, 1, 2>(a, stream);
-        return launch_cfg<Tag, 4, 4, 12, 2, 1, 3, 1, 2>(a, stream);
+        if (a.cout % 256 == 0) return launch_cfg_pool<Tag, 4, 4, 12, 2, 1, 3, 1, 2>(a, stream);
+        if (a.cout % 128 == 0) return launch_cfg_pool<Tag, 4, 4, 12, 2, 2, 3, 2, 2>(a, stream);
+        if (a.cout % 64 == 0) return launch_cfg_pool<Tag, 4, 4, 12, 2, 2, 3, 1, 2>(a, stream);
+        return launch_cfg_pool<Tag, 4, 4, 12, 2, 1, 3, 1, 2>(a, stream);
     }
     // 6^3 level: the whole patch is one tile; 32-cout slices on four waves give the most
     // workgroups (16 patches x 8 slices for 256 couts)
     return launch_cfg<Tag, 6, 6, 6, 4, 1, 2, 1, 2>(a, stream);
 }
 
-bool conv_can_fuse_pool(int cout, int d, int h, int w) {
-    // the layers launch_typed sends to the z-column kernel, on even patch sizes
-    return cout % 64 != 0 && w >= 16 && w % 16 == 0 && d % 2 == 0 && h % 2 == 0;
+bool conv_can_fuse_pool(int dtype, int cout, int d, int h, int w) {
+    if (d % 2 != 0 || h % 2 != 0 || w % 2 != 0) return false;
+    // the layers launch_typed sends to the z-column kernel (any dtype) ...
+    if (cout % 64 != 0 && w >= 16 && w % 16 == 0) return true;
+    // ... and, in the 16-bit modes, every other tile shape but the single-tile 6^3 one
+    return dtype != EXASPIM_DT_F32 && w > 6;
 }
 
 bool conv_can_fuse_head(int cout, int w, int head_oc) {
@@ -1986,8 +2093,9 @@ int launch_conv3x3x3(int dtype, const ConvArgs& a_in, hipStream_t stream) {
     EXA_CHECK_ARG(a.slope >= 0.f && a.slope <= 1.f, "conv: LeakyReLU slope %g outside [0, 1]", a.slope);
     if (int rc = resolve_region(a)) return rc;
     const bool whole = a.ext[0] == a.d && a.ext[1] == a.h && a.ext[2] == a.w;
-    EXA_CHECK_ARG(!a.pool_dst || (conv_can_fuse_pool(a.cout, a.d, a.h, a.w) && !a.head_out && whole),
-                  "conv: fused max-pool needs a 32-cout-slice layer on an even, untrimmed patch");
+    EXA_CHECK_ARG(!a.pool_dst || (conv_can_fuse_pool(dtype, a.cout, a.d, a.h, a.w) && !a.head_out && whole),
+                  "conv: fused max-pool needs an even, untrimmed patch (16-bit modes: wider than 6 voxels; "
+                  "float32: a 32-cout-slice layer)");
     EXA_CHECK_ARG(!a.head_out || conv_can_fuse_head(a.cout, a.w, a.head_oc),
                   "conv: fused head needs cout 32, w %% 16 == 0, 1..4 outputs");
     {   // the staging loads address one patch of one source with 32-bit buffer offsets

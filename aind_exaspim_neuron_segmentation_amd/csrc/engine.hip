@@ -6,6 +6,7 @@
 // B[l] (ping-pong) -- each sized for the widest tensor stored at that level.
 
 #include <algorithm>
+#include <cstdlib>
 #include <new>
 #include <string_view>
 
@@ -101,15 +102,23 @@ static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, in
     // With the head fused, voxels within "trim" of a patch face are never read again:
     // up4.3 skips them, and up4.0 everything its 3x3x3 consumer does not reach.
     const bool trimmed = fuse_head && trim > 0 && 2 * trim < d && 2 * trim < h && 2 * trim < w;
-    const bool fuse_pool = conv_can_fuse_pool(p.conv[0].cout, d, h, w);
+    // conv 2l (inc.3, down1.3, down2.3, down3.3) can write its own max-pool, the input of level l + 1
+    // (EXASPIM_SEPARATE_POOL, read per call: run the stand-alone max-pool launches instead -- the
+    // tests hold the two to each other bit for bit)
+    const char* sep = getenv("EXASPIM_SEPARATE_POOL");
+    const bool separate_pool = sep && sep[0] == '1';
+    const bool separate_deep = sep && sep[0] == '2';   // measurement aid: only inc.3 keeps its pool
+    bool fuse_pool[4];
+    for (int l = 0; l < 4; ++l)
+        fuse_pool[l] = !separate_pool && !(separate_deep && l > 0) && conv_can_fuse_pool(p.dtype, p.conv[2 * l].cout, d >> l, h >> l, w >> l);
     auto conv = [&](int idx, const void* sa, const void* sb, void* dst, int l) -> int {
         const ConvLayer& L = p.conv[idx];
         ConvArgs a;
-        // inc.3 can write its own 2x2x2 max-pool (the input of down1) next to its output
+        // the last conv of an encoder level writes its 2x2x2 max-pool (the next level's input) too
         // split-K scratch: the zero-bordered input copy is dead once inc.0 has run
         a.partial = reinterpret_cast<float*>(base + ws.xpad);
         a.partial_patch_bytes = (size_t)(d + 2) * (h + 2) * (w + 2) * sizeof(float);
-        if (idx == 0 && fuse_pool) a.pool_dst = A(1);
+        if (idx <= 6 && idx % 2 == 0 && fuse_pool[idx / 2]) a.pool_dst = A(idx / 2 + 1);
         // up4.3 produces [trim, size - trim), up4.0 one voxel more on every face
         const int margin = !trimmed ? 0 : idx == kNumMfmaConvs - 1 ? trim : idx == kNumMfmaConvs - 2 ? trim - 1 : 0;
         const int full[3] = {d >> l, h >> l, w >> l};
@@ -182,7 +191,7 @@ static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, in
     for (int l = 1; l <= 4; ++l) {
         const ConvLayer& L0 = p.conv[2 * l - 1];
         const void* prev = skip(l - 1);
-        if (!(l == 1 && fuse_pool))
+        if (!fuse_pool[l - 1])
             RUN(launch_maxpool2(dt, prev, A(l), n, d >> (l - 1), h >> (l - 1), w >> (l - 1), L0.ca,
                                 stream));
         RUN(conv(2 * l - 1, A(l), nullptr, B(l), l));

@@ -666,3 +666,28 @@ assert err.max() < 1e-3
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     print(out.stdout[-400:], out.stderr[-400:])
     assert out.returncode == 0
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16", "fp32"])
+@pytest.mark.parametrize("wm,shape,n", [(1, (96, 96, 96), 2), (1, (48, 64, 80), 3), (0.5, (32, 48, 64), 2),
+                                        (2, (16, 32, 48), 1), (0.25, (96, 32, 16), 5)])
+def test_fused_max_pool_equals_the_separate_launch(dev, oracle, dtype, wm, shape, n, monkeypatch):
+    """The last convolution of every encoder level writes the level's MaxPool3d(2)
+    (unet3d.py:194-196) from its epilogue (z-column kernel: wave-local; t14 kernel: the
+    tile's output groups parked in LDS, 16-bit modes). EXASPIM_SEPARATE_POOL=1 (read per
+    call) runs the stand-alone max-pool launches instead: the logits must be the same bits
+    -- a maximum of stored values either way -- over the tile shapes of all pyramid levels
+    (96/48/24/12, 80/40/20/10, 64/32/16/8 ... wide), widths and dtypes."""
+    from aind_exaspim_neuron_segmentation_amd.machine_learning.unet3d import UNet3D
+
+    sd = synthetic.synth_state_dict(3, wm, seed=23)
+    model = UNet3D(output_channels=3, width_multiplier=wm, compute_dtype=dtype)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    model = model.to(dev).eval()
+    x = normalized_input(oracle, shape, seed=31, n=n).to(dev)
+    fused = model(x).cpu().numpy()
+    monkeypatch.setenv("EXASPIM_SEPARATE_POOL", "1")
+    separate = model(x).cpu().numpy()
+    monkeypatch.delenv("EXASPIM_SEPARATE_POOL")
+    assert np.isfinite(fused).all()
+    assert np.array_equal(fused, separate)
