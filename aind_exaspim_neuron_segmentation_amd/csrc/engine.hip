@@ -81,9 +81,10 @@ static Workspace make_workspace(const UNetPlan& p, int n, int d, int h, int w) {
     return ws;
 }
 
+// x: float32 patches, or (x == nullptr) x_prepared: the first convolution's operand layout
 static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, int h, int w,
                    int apply_sigmoid, int trim, void* workspace, size_t workspace_bytes,
-                   hipStream_t stream) {
+                   hipStream_t stream, const void* x_prepared = nullptr) {
     const UNetPlan& p = e->plan;
     const Workspace ws = make_workspace(p, n, d, h, w);
     if (workspace_bytes < ws.bytes) {
@@ -183,7 +184,8 @@ static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, in
 #define RUN(expr) do { rc = (expr); if (rc) return rc; } while (0)
 
     // encoder (unet3d.py:93-97)
-    RUN(launch_conv_first(dt, x, reinterpret_cast<float*>(base + ws.xpad),
+    RUN(launch_conv_first(dt, x, x ? reinterpret_cast<float*>(base + ws.xpad)
+                                   : const_cast<float*>(static_cast<const float*>(x_prepared)),
                           reinterpret_cast<const float*>(e->packed + p.first_w_off),
                           reinterpret_cast<const float*>(e->packed + p.first_b_off), A(0), n, d,
                           h, w, p.c0p, kLeakySlope, stream));
@@ -359,6 +361,31 @@ extern "C" int exaspim_unet_forward(exaspim_unet* h, const float* x_dev, float* 
                   d, hgt, w);
     return forward(h, x_dev, out_dev, n, d, hgt, w, apply_sigmoid, 0, workspace_dev, workspace_bytes,
                    (hipStream_t)stream);
+}
+
+extern "C" int exaspim_unet_input_layout(const exaspim_unet* h) {
+    if (!h) return EXASPIM_E_INVALID;
+    switch (h->plan.dtype) {
+        case EXASPIM_DT_F32: return EXASPIM_IN_PADDED_F32;
+        case EXASPIM_DT_F16: return EXASPIM_IN_PADDED_SPLIT_F16;
+        case EXASPIM_DT_BF16: return EXASPIM_IN_PADDED_SPLIT_BF16;
+    }
+    return EXASPIM_E_INVALID;
+}
+
+extern "C" int exaspim_unet_forward_prepared(exaspim_unet* h, const void* x_prepared_dev, float* out_dev,
+                                             int32_t n, int32_t d, int32_t hgt, int32_t w,
+                                             int32_t apply_sigmoid, int32_t trim,
+                                             void* workspace_dev, size_t workspace_bytes,
+                                             void* stream) {
+    EXA_CHECK_ARG(h && x_prepared_dev && out_dev && workspace_dev, "forward: NULL pointer");
+    EXA_CHECK_ARG(n > 0, "forward: empty batch");
+    EXA_CHECK_ARG(trim >= 0, "forward: negative trim %d", trim);
+    EXA_CHECK_ARG(level_dims_ok(d, hgt, w),
+                  "forward: patch %dx%dx%d: every dimension must be a positive multiple of 16",
+                  d, hgt, w);
+    return forward(h, nullptr, out_dev, n, d, hgt, w, apply_sigmoid, trim, workspace_dev,
+                   workspace_bytes, (hipStream_t)stream, x_prepared_dev);
 }
 
 extern "C" int exaspim_unet_forward_trimmed(exaspim_unet* h, const float* x_dev, float* out_dev,

@@ -795,7 +795,8 @@ int launch_conv_first(int dtype, const float* x, float* xpad, const float* w, co
     EXA_CHECK_ARG((long long)n * (d + 2) <= 65535 && h + 2 <= 65535, "conv_first: grid too large");
     const unsigned pad_blocks = (unsigned)((long long)n * (d + 2));
     unsigned* const xsplit = reinterpret_cast<unsigned*>(xpad);   // 16-bit modes: hi | lo << 16 per voxel
-    switch (dtype) {
+    // x == nullptr: xpad already holds the operand layout (exaspim_gather_patches_as wrote it)
+    if (x) switch (dtype) {
         case EXASPIM_DT_F32: pad_input_kernel<<<pad_blocks, 256, 0, stream>>>(x, xpad, d, h, wd); break;
         case EXASPIM_DT_BF16: pad_split_kernel<BF16T><<<pad_blocks, 256, 0, stream>>>(x, xsplit, d, h, wd); break;
         case EXASPIM_DT_F16: pad_split_kernel<F16T><<<pad_blocks, 256, 0, stream>>>(x, xsplit, d, h, wd); break;

@@ -125,18 +125,46 @@ template <> __device__ __forceinline__ double load_voxel<EXASPIM_VOX_U16>(const 
 template <> __device__ __forceinline__ double load_voxel<EXASPIM_VOX_I16>(const void* v, size_t i) { return (double)static_cast<const int16_t*>(v)[i]; }
 template <> __device__ __forceinline__ double load_voxel<EXASPIM_VOX_F32>(const void* v, size_t i) { return (double)static_cast<const float*>(v)[i]; }
 
-// Grid: x = voxels of one patch row, y = patch row, z = patch * depth.
-template <int VOX>
+// How a gathered value leaves the kernel (LAYOUT = EXASPIM_IN_*): the float32 patch the ABI's
+// forward takes, or the first convolution's own operand layout -- a (pz + 2, py + 2, px + 2)
+// copy with a zero border, float32 or every voxel already split into two 16-bit parts,
+// hi | lo << 16 (what pad_input_kernel / pad_split_kernel of layers.hip make of the float32
+// patch, bit for bit) -- so that the padding pass and a 4-byte-per-voxel round trip disappear.
+template <int LAYOUT>
+__device__ __forceinline__ void emit_input(float* out, size_t i, float r) {
+    if (LAYOUT == EXASPIM_IN_F32 || LAYOUT == EXASPIM_IN_PADDED_F32) {
+        out[i] = r;
+    } else if (LAYOUT == EXASPIM_IN_PADDED_SPLIT_F16) {
+        const _Float16 hi = (_Float16)r;
+        const _Float16 lo = (_Float16)(r - (float)hi);
+        reinterpret_cast<unsigned*>(out)[i] = (unsigned)__builtin_bit_cast(unsigned short, hi) |
+                                              ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+    } else {
+        const unsigned short hi = __builtin_bit_cast(unsigned short, (__bf16)r);
+        const unsigned short lo = __builtin_bit_cast(unsigned short, (__bf16)(r - __uint_as_float((unsigned)hi << 16)));
+        reinterpret_cast<unsigned*>(out)[i] = (unsigned)hi | ((unsigned)lo << 16);
+    }
+}
+
+// Grid: x = voxels of one (padded) patch row, y = row, z = patch * (padded) depth.
+template <int VOX, int LAYOUT>
 __global__ __launch_bounds__(128) void gather_kernel(const void* __restrict__ vol,
                                                      exaspim_block blk,
                                                      const int* __restrict__ starts, int pz,
                                                      int py, int px, double clip, int has_clip,
                                                      double mn, double denom,
                                                      float* __restrict__ out) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= px) return;
-    const int y = blockIdx.y;
-    const int p = blockIdx.z / pz, z = blockIdx.z - p * pz;
+    constexpr int B = LAYOUT == EXASPIM_IN_F32 ? 0 : 1;   // border
+    const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ox >= px + 2 * B) return;
+    const int oy = blockIdx.y;
+    const int p = blockIdx.z / (pz + 2 * B), oz = blockIdx.z - p * (pz + 2 * B);
+    const size_t oidx = (((size_t)p * (pz + 2 * B) + oz) * (py + 2 * B) + oy) * (px + 2 * B) + ox;
+    const int x = ox - B, y = oy - B, z = oz - B;
+    if (B && ((unsigned)x >= (unsigned)px || (unsigned)y >= (unsigned)py || (unsigned)z >= (unsigned)pz)) {
+        out[oidx] = 0.f;    // (all-zero bits in the split layouts as well)
+        return;
+    }
     const int sz = starts[3 * p], sy = starts[3 * p + 1], sx = starts[3 * p + 2];
     // in-volume extent of the patch (img_util.py:424-428), then reflect
     const int nz = min(sz + pz, blk.global[0]) - sz;
@@ -154,14 +182,14 @@ __global__ __launch_bounds__(128) void gather_kernel(const void* __restrict__ vo
         q = fmin(fmax(q, 0.0), 1.0);         // np.clip(img, 0, 1)
         r = (float)q;                        // cast on assignment (inference.py:191)
     }
-    out[(((size_t)p * pz + z) * py + y) * px + x] = r;
+    emit_input<LAYOUT>(out, oidx, r);
 }
 
 // Unsigned integer volumes with a brightness clip take at most clip + 1 distinct values
 // after np.minimum (inference.py:79), so the float64 normalisation is evaluated once per
 // value into an LDS table (the same expression, entry for entry) and a voxel costs one
 // lookup instead of a float64 division. One block = one (patch, z) plane.
-template <typename V>
+template <typename V, int LAYOUT>
 __global__ __launch_bounds__(256) void gather_lut_kernel(const V* __restrict__ vol, exaspim_block blk,
                                                          const int* __restrict__ starts, int pz,
                                                          int py, int px, int clip, double mn,
@@ -173,16 +201,26 @@ __global__ __launch_bounds__(256) void gather_lut_kernel(const V* __restrict__ v
         lut[v] = (float)q;                     // cast on assignment (inference.py:191)
     }
     __syncthreads();
-    const int p = blockIdx.x / pz, z = blockIdx.x - p * pz;
+    constexpr int B = LAYOUT == EXASPIM_IN_F32 ? 0 : 1;   // border: one block per PADDED plane
+    const int p = blockIdx.x / (pz + 2 * B), z = blockIdx.x - p * (pz + 2 * B) - B;
+    const int opx = px + 2 * B, oplane_vox = (py + 2 * B) * opx;
+    float* const oplane = out + (size_t)blockIdx.x * oplane_vox;
+    if (B && (unsigned)z >= (unsigned)pz) {
+        for (int i = threadIdx.x; i < oplane_vox; i += blockDim.x) oplane[i] = 0.f;
+        return;
+    }
     const int sz = starts[3 * p], sy = starts[3 * p + 1], sx = starts[3 * p + 2];
     const int nz = min(sz + pz, blk.global[0]) - sz;
     const int ny = min(sy + py, blk.global[1]) - sy;
     const int nx = min(sx + px, blk.global[2]) - sx;
     const int lz = sz + reflect_index(z, nz) - blk.origin[0];
     const bool zok = (unsigned)lz < (unsigned)blk.dims[0];
-    float* const oplane = out + ((size_t)p * pz + z) * py * px;
-    for (int i = threadIdx.x; i < py * px; i += blockDim.x) {
-        const int y = i / px, x = i - y * px;
+    for (int i = threadIdx.x; i < oplane_vox; i += blockDim.x) {
+        const int y = i / opx - B, x = i - (y + B) * opx - B;
+        if (B && ((unsigned)y >= (unsigned)py || (unsigned)x >= (unsigned)px)) {
+            oplane[i] = 0.f;
+            continue;
+        }
         const int ly = sy + reflect_index(y, ny) - blk.origin[1];
         const int lx = sx + reflect_index(x, nx) - blk.origin[2];
         float r = 0.f;
@@ -190,7 +228,7 @@ __global__ __launch_bounds__(256) void gather_lut_kernel(const V* __restrict__ v
             const int v = (int)vol[((size_t)lz * blk.dims[1] + ly) * blk.dims[2] + lx];
             r = lut[v < clip ? v : clip];
         }
-        oplane[i] = r;
+        emit_input<LAYOUT>(oplane, (size_t)i, r);
     }
 }
 
@@ -429,35 +467,31 @@ extern "C" int exaspim_histogram(const void* vol_dev, int32_t vox_dtype, size_t 
     return EXASPIM_OK;
 }
 
-extern "C" int exaspim_gather_patches(const void* vol_dev, int32_t vox_dtype,
-                                      const exaspim_block* blk, const int32_t* starts_dev,
-                                      int32_t n, const int32_t patch[3], double clip,
-                                      int32_t has_clip, double mn, double denom, float* out_dev,
-                                      void* stream) {
-    if (int rc = check_block(blk, "gather")) return rc;
-    EXA_CHECK_ARG(vol_dev && starts_dev && out_dev && patch, "gather: NULL pointer");
-    EXA_CHECK_ARG(n > 0 && patch[0] > 0 && patch[1] > 0 && patch[2] > 0, "gather: empty batch");
-    EXA_CHECK_ARG((long long)n * patch[0] <= 65535 && patch[1] <= 65535, "gather: grid too large");
-    hipStream_t s = (hipStream_t)stream;
+template <int LAYOUT>
+static int gather_launch(const void* vol_dev, int32_t vox_dtype, const exaspim_block* blk,
+                         const int32_t* starts_dev, int32_t n, const int32_t patch[3], double clip,
+                         int32_t has_clip, double mn, double denom, float* out_dev, hipStream_t s) {
+    constexpr int B = LAYOUT == EXASPIM_IN_F32 ? 0 : 1;
+    EXA_CHECK_ARG((long long)n * (patch[0] + 2 * B) <= 65535 && patch[1] + 2 * B <= 65535, "gather: grid too large");
     // table path: unsigned integers clipped to a small integer maximum
     if (has_clip && clip >= 0.0 && clip <= 16383.0 && clip == (double)(int)clip &&
         (vox_dtype == EXASPIM_VOX_U8 || vox_dtype == EXASPIM_VOX_U16)) {
         const int ci = (int)clip;
         const size_t lds = ((size_t)ci + 1) * sizeof(float);
-        const unsigned blocks = (unsigned)((long long)n * patch[0]);
+        const unsigned blocks = (unsigned)((long long)n * (patch[0] + 2 * B));
         if (vox_dtype == EXASPIM_VOX_U8)
-            gather_lut_kernel<uint8_t><<<blocks, 256, lds, s>>>(static_cast<const uint8_t*>(vol_dev), *blk,
-                                                               starts_dev, patch[0], patch[1], patch[2], ci,
-                                                               mn, denom, out_dev);
+            gather_lut_kernel<uint8_t, LAYOUT><<<blocks, 256, lds, s>>>(
+                static_cast<const uint8_t*>(vol_dev), *blk, starts_dev, patch[0], patch[1], patch[2], ci, mn,
+                denom, out_dev);
         else
-            gather_lut_kernel<uint16_t><<<blocks, 256, lds, s>>>(static_cast<const uint16_t*>(vol_dev), *blk,
-                                                                starts_dev, patch[0], patch[1], patch[2], ci,
-                                                                mn, denom, out_dev);
+            gather_lut_kernel<uint16_t, LAYOUT><<<blocks, 256, lds, s>>>(
+                static_cast<const uint16_t*>(vol_dev), *blk, starts_dev, patch[0], patch[1], patch[2], ci, mn,
+                denom, out_dev);
         EXA_CHECK_HIP(hipGetLastError());
         return EXASPIM_OK;
     }
-    const dim3 grid((patch[2] + 127) / 128, patch[1], n * patch[0]);
-#define GATHER(V) gather_kernel<V><<<grid, 128, 0, s>>>(vol_dev, *blk, starts_dev, patch[0], patch[1], patch[2], clip, has_clip, mn, denom, out_dev)
+    const dim3 grid((patch[2] + 2 * B + 127) / 128, patch[1] + 2 * B, n * (patch[0] + 2 * B));
+#define GATHER(V) gather_kernel<V, LAYOUT><<<grid, 128, 0, s>>>(vol_dev, *blk, starts_dev, patch[0], patch[1], patch[2], clip, has_clip, mn, denom, out_dev)
     switch (vox_dtype) {
         case EXASPIM_VOX_U8: GATHER(EXASPIM_VOX_U8); break;
         case EXASPIM_VOX_U16: GATHER(EXASPIM_VOX_U16); break;
@@ -470,6 +504,39 @@ extern "C" int exaspim_gather_patches(const void* vol_dev, int32_t vox_dtype,
 #undef GATHER
     EXA_CHECK_HIP(hipGetLastError());
     return EXASPIM_OK;
+}
+
+extern "C" int exaspim_gather_patches_as(const void* vol_dev, int32_t vox_dtype,
+                                         const exaspim_block* blk, const int32_t* starts_dev,
+                                         int32_t n, const int32_t patch[3], double clip,
+                                         int32_t has_clip, double mn, double denom, int32_t layout,
+                                         void* out_dev, void* stream) {
+    if (int rc = check_block(blk, "gather")) return rc;
+    EXA_CHECK_ARG(vol_dev && starts_dev && out_dev && patch, "gather: NULL pointer");
+    EXA_CHECK_ARG(n > 0 && patch[0] > 0 && patch[1] > 0 && patch[2] > 0, "gather: empty batch");
+    hipStream_t s = (hipStream_t)stream;
+    float* const out = static_cast<float*>(out_dev);
+    switch (layout) {
+        case EXASPIM_IN_F32:
+            return gather_launch<EXASPIM_IN_F32>(vol_dev, vox_dtype, blk, starts_dev, n, patch, clip, has_clip, mn, denom, out, s);
+        case EXASPIM_IN_PADDED_F32:
+            return gather_launch<EXASPIM_IN_PADDED_F32>(vol_dev, vox_dtype, blk, starts_dev, n, patch, clip, has_clip, mn, denom, out, s);
+        case EXASPIM_IN_PADDED_SPLIT_F16:
+            return gather_launch<EXASPIM_IN_PADDED_SPLIT_F16>(vol_dev, vox_dtype, blk, starts_dev, n, patch, clip, has_clip, mn, denom, out, s);
+        case EXASPIM_IN_PADDED_SPLIT_BF16:
+            return gather_launch<EXASPIM_IN_PADDED_SPLIT_BF16>(vol_dev, vox_dtype, blk, starts_dev, n, patch, clip, has_clip, mn, denom, out, s);
+    }
+    set_error("gather: unknown input layout %d", layout);
+    return EXASPIM_E_INVALID;
+}
+
+extern "C" int exaspim_gather_patches(const void* vol_dev, int32_t vox_dtype,
+                                      const exaspim_block* blk, const int32_t* starts_dev,
+                                      int32_t n, const int32_t patch[3], double clip,
+                                      int32_t has_clip, double mn, double denom, float* out_dev,
+                                      void* stream) {
+    return exaspim_gather_patches_as(vol_dev, vox_dtype, blk, starts_dev, n, patch, clip, has_clip, mn,
+                                     denom, EXASPIM_IN_F32, out_dev, stream);
 }
 
 extern "C" int exaspim_stitch_accumulate(const float* pred_dev, const int32_t* starts_dev,

@@ -271,6 +271,66 @@ class UNet3D(nn.Module):
             )
         return out
 
+    def input_layout(self, device=None):
+        """
+        Layout code (_native.IN_PADDED_*) of the input run_prepared() takes: the
+        first convolution's own operand layout for this compute dtype.
+        """
+        device = next(self.parameters()).device if device is None else device
+        with torch.cuda.device(device):
+            self._ensure_engine(device)
+        code = _native.lib().exaspim_unet_input_layout(self._engine)
+        if code < 0:
+            raise RuntimeError("exaspim_unet_input_layout failed")
+        return int(code)
+
+    def run_prepared(self, prepared, shape, apply_sigmoid=False, out=None, trim=0):
+        """
+        run() from a batch the gather kernel has already written in the first
+        convolution's operand layout (inference._get_batch_inputs(..., layout=
+        self.input_layout())): a contiguous 4-byte-per-voxel device tensor of shape
+        (B, D + 2, H + 2, W + 2). Same bits as run() on the float32 patches.
+
+        Parameters
+        ----------
+        prepared : torch.Tensor
+            The prepared batch.
+        shape : Tuple[int]
+            (B, D, H, W) of the patches.
+        """
+        if self.training:
+            raise RuntimeError(
+                "UNet3D (MI355X) implements eval-mode inference only; call .eval()"
+            )
+        n, d, h, w = (int(v) for v in shape)
+        if (not prepared.is_cuda or not prepared.is_contiguous() or prepared.element_size() != 4
+                or tuple(prepared.shape) != (n, d + 2, h + 2, w + 2)):
+            raise RuntimeError(
+                f"prepared input must be a contiguous 4-byte device tensor of shape {(n, d + 2, h + 2, w + 2)}"
+            )
+        if d % 16 or h % 16 or w % 16:
+            raise RuntimeError(
+                "Sizes of tensors must match: patch dimensions must be multiples of 16, "
+                f"got {(d, h, w)}"
+            )
+        device = prepared.device
+        with torch.cuda.device(device):
+            self._ensure_engine(device)
+            stream = torch.cuda.current_stream(device).cuda_stream
+            ws = self._get_workspace(n, d, h, w, device, stream)
+            if out is None:
+                out = torch.empty(
+                    (n, self.output_channels, d, h, w), dtype=torch.float32, device=device
+                )
+            _native.check(
+                _native.lib().exaspim_unet_forward_prepared(
+                    self._engine, prepared.data_ptr(), out.data_ptr(), n, d, h, w,
+                    1 if apply_sigmoid else 0, int(trim), ws.data_ptr(), ws.numel(), stream,
+                ),
+                "exaspim_unet_forward_prepared",
+            )
+        return out
+
     def forward(self, x):
         """
         Forward pass: (B, 1, D, H, W) -> logits (B, output_channels, D, H, W).

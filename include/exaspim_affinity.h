@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 /* 3: exaspim_export_f16 added (entry points are only ever added within a major line) */
-#define EXASPIM_ABI_VERSION 3
+#define EXASPIM_ABI_VERSION 4
 
 /* error codes */
 #define EXASPIM_OK 0
@@ -143,6 +143,18 @@ int exaspim_unet_forward_trimmed(exaspim_unet* h, const float* x_dev, float* out
                                  int32_t apply_sigmoid, int32_t trim, void* workspace_dev,
                                  size_t workspace_bytes, void* stream);
 
+/* The same forward pass from a batch that exaspim_gather_patches_as has already written in
+ * the first convolution's operand layout (exaspim_unet_input_layout: EXASPIM_IN_PADDED_F32
+ * for a float32 engine, EXASPIM_IN_PADDED_SPLIT_F16 / _BF16 for the 16-bit ones):
+ * x_prepared_dev is (n, d + 2, hgt + 2, w + 2) 4-byte words. _get_batch_inputs feeding
+ * model(inputs) (inference.py:155-157) without the float32 patch tensor in between: one
+ * launch and an 8-byte-per-voxel round trip less per batch; out_dev gets the same bits. */
+int exaspim_unet_input_layout(const exaspim_unet* h);
+int exaspim_unet_forward_prepared(exaspim_unet* h, const void* x_prepared_dev, float* out_dev,
+                                  int32_t n, int32_t d, int32_t hgt, int32_t w,
+                                  int32_t apply_sigmoid, int32_t trim, void* workspace_dev,
+                                  size_t workspace_bytes, void* stream);
+
 /* Measurement hooks (bench.py's roofline leg). timing_begin arms HIP-event
  * timing, on the launch stream, of the MFMA convolutions whose bit is set in
  * conv_mask (bit i = i-th 3x3x3 conv after inc.0 in state_dict order: inc.3,
@@ -177,6 +189,20 @@ int exaspim_histogram(const void* vol_dev, int32_t vox_dtype, size_t n,
  * float64, with v taken from the volume block and the part of the patch that
  * sticks out of the GLOBAL volume filled by numpy 'reflect' padding of the
  * in-volume part (img_util.py:378-379). denom = mx - mn + 1e-8. */
+/* Layouts exaspim_gather_patches_as can write a batch in: the float32 patches above, or a
+ * copy with a one-voxel zero border, (n, patch[0] + 2, patch[1] + 2, patch[2] + 2) 4-byte
+ * words, holding the same float32 values or every value v split for the 16-bit matrix pipe,
+ * bits(hi) | bits(lo) << 16 with hi = half(v), lo = half(v - float(hi)) (IEEE half or
+ * bfloat16) -- what the engine's own padding pass makes of the float32 patch. */
+#define EXASPIM_IN_F32 0
+#define EXASPIM_IN_PADDED_F32 1
+#define EXASPIM_IN_PADDED_SPLIT_F16 2
+#define EXASPIM_IN_PADDED_SPLIT_BF16 3
+int exaspim_gather_patches_as(const void* vol_dev, int32_t vox_dtype,
+                              const exaspim_block* blk, const int32_t* starts_dev,
+                              int32_t n, const int32_t patch[3], double clip,
+                              int32_t has_clip, double mn, double denom, int32_t layout,
+                              void* out_dev, void* stream);
 int exaspim_gather_patches(const void* vol_dev, int32_t vox_dtype,
                            const exaspim_block* blk, const int32_t* starts_dev,
                            int32_t n, const int32_t patch[3], double clip,

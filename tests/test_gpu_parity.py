@@ -691,3 +691,60 @@ def test_fused_max_pool_equals_the_separate_launch(dev, oracle, dtype, wm, shape
     monkeypatch.delenv("EXASPIM_SEPARATE_POOL")
     assert np.isfinite(fused).all()
     assert np.array_equal(fused, separate)
+
+
+def _split_words(x, kind):
+    """hi | lo << 16 of float32 values, hi = half(x), lo = half(x - float(hi)) (numpy)."""
+    if kind == "f16":
+        hi = x.astype(np.float16)
+        lo = (x - hi.astype(np.float32)).astype(np.float16)
+        return hi.view(np.uint16).astype(np.uint32) | (lo.view(np.uint16).astype(np.uint32) << 16)
+
+    def bf16(v):      # round to nearest even on the upper 16 bits
+        u = np.ascontiguousarray(v, dtype=np.float32).view(np.uint32).astype(np.uint64)
+        return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32)
+
+    hi = bf16(x)
+    lo = bf16(x - (hi << 16).astype(np.uint32).view(np.float32))
+    return hi | (lo << 16)
+
+
+@pytest.mark.parametrize("vox,clip", [(np.uint16, 1000), (np.float32, None), (np.int16, 700.5), (np.uint8, 200)])
+def test_gather_writes_the_first_convolutions_operand_layout(dev, vox, clip):
+    """exaspim_gather_patches_as: the zero-bordered float32 copy and the hi | lo << 16 split
+    copies (IEEE half, bfloat16) of a batch equal what numpy makes of the float32 batch the
+    reference-shaped gather returns -- table path, generic path, reflected and ragged patches."""
+    from aind_exaspim_neuron_segmentation_amd import _native, inference
+
+    rng = np.random.default_rng(3)
+    vol = (rng.random((41, 37, 52)) * 1500).astype(vox)
+    volume = inference.DeviceVolume.from_array(vol, dev)
+    starts = torch.tensor([[0, 0, 0], [16, 8, 24], [32, 24, 40], [9, 5, 20]], dtype=torch.int32, device=dev)
+    patch = (32, 16, 48)
+    c, _ = inference._effective_clip(volume.np_dtype, clip, volume.storage_dtype)
+    kw = dict(clip=c, mn=3.0, mx=977.0)
+    plain = inference._get_batch_inputs(volume, starts, patch, dev, **kw).cpu().numpy()[:, 0]
+    padded = np.zeros((4, 34, 18, 50), np.float32)
+    padded[:, 1:-1, 1:-1, 1:-1] = plain
+    got = inference._get_batch_inputs(volume, starts, patch, dev, layout=_native.IN_PADDED_F32, **kw)
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), padded.view(np.uint32))
+    for layout, kind in ((_native.IN_PADDED_SPLIT_F16, "f16"), (_native.IN_PADDED_SPLIT_BF16, "bf16")):
+        got = inference._get_batch_inputs(volume, starts, patch, dev, layout=layout, **kw)
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), _split_words(padded, kind)), kind
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16", "bf16"])
+def test_prepared_gather_path_does_not_change_a_bit(dev, dtype, monkeypatch):
+    """predict() lets the gather kernel write the first convolution's operand layout
+    (exaspim_unet_forward_prepared); EXASPIM_PLAIN_GATHER=1 goes through the float32 batch
+    and the engine's own padding pass, like model(inputs) does. Same bits."""
+    from aind_exaspim_neuron_segmentation_amd import inference
+
+    model, _ = make_model(dev, seed=9, compute_dtype=dtype)
+    vol = synthetic.synth_volume((72, 88, 104), seed=5)
+    kw = dict(batch_size=5, patch_shape=(32, 48, 32), overlap=(8, 8, 8), trim=4, verbose=False)
+    fused = inference.predict(vol, model, **kw)
+    monkeypatch.setenv("EXASPIM_PLAIN_GATHER", "1")
+    plain = inference.predict(vol, model, **kw)
+    monkeypatch.delenv("EXASPIM_PLAIN_GATHER")
+    assert fused.any() and np.array_equal(fused, plain)

@@ -33,7 +33,7 @@ def test_header_symbols_are_exported(lib):
     assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.exaspim_abi_version() == 3
+    assert lib.exaspim_abi_version() == 4
 
 
 def test_param_count_matches_state_dict(lib):
