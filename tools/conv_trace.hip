@@ -3,7 +3,7 @@
 // tools/analyze_trace.py can rebuild a per-CU timeline of where a workgroup's
 // life goes (prologue latency, MFMA loop, barriers, epilogue).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DEXASPIM_TRACE tools/conv_trace.hip \
-//         aind_exaspim_neuron_segmentation_amd/csrc/plan.cpp -x hip -o tools/conv_trace
+//         aind_exaspim_neuron_segmentation_amd/csrc/plan.cpp aind_exaspim_neuron_segmentation_amd/csrc/layers.hip -x hip -o tools/conv_trace
 //   tools/conv_trace <ca> <cb> <cout> <edge> <batch> <out.bin> [kernel variant]
 #include "../aind_exaspim_neuron_segmentation_amd/csrc/conv3d.hip"
 
