@@ -192,11 +192,25 @@ def host_to_host(model, args, edge):
     phases = {}
     inference.predict_streaming(vol, model, batch_size=args.batch, verbose=False, n_streams=args.streams,
                                 timings=phases)
+    piped = None
+    if args.pipelined_streams > 1 and args.streams == 1:
+        # the same call with predict()'s n_streams option (bit-identical result)
+        ptimes = []
+        for _ in range(2):
+            del out
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = inference.predict(vol, model, batch_size=args.batch, verbose=False,
+                                    n_streams=args.pipelined_streams)
+            ptimes.append(time.perf_counter() - t0)
+        piped = {"streams": args.pipelined_streams, "value": float(edge) ** 3 / min(ptimes),
+                 "ms_per_step": min(ptimes) * 1e3}
     return {
         "phases_s": {k: round(v, 4) for k, v in phases.items()},
         "value": float(edge) ** 3 / dt,
         "unit": "voxels/s",
         "ms_per_step": dt * 1e3,
+        "pipelined": piped,
         "first_call_ms": times[0] * 1e3,
         "what": "inference.predict(numpy uint16 -> numpy float32 (3, D, H, W)): chunked upload + "
                 "histogram, finished 64-plane slabs downloaded to pinned memory on a copy stream and "
