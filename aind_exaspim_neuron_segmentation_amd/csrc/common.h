@@ -34,6 +34,20 @@ const char* get_error();
         }                                                                    \
     } while (0)
 
+// ---- device helper shared by the convolution epilogues ------------------------
+// One voxel's 16-channel record of a chunk plane (32 B in a 16-bit type) leaves the accumulators
+// of a 32 x 32 MFMA tile split over the two half-waves: lane r holds channels 8q .. 8q + 3 of its
+// voxel, lane r + 32 channels 8q + 4 .. 8q + 7 (q = 0 .. 3). v_permlane32_swap exchanges the upper
+// half of group q with the lower half of group q + 1, after which lane r holds the record's first
+// 16 bytes (channels 0 .. 7 of the pair) and lane r + 32 the second 16 (channels 8 .. 15): one
+// 16-byte store per lane and chunk plane, 32 whole records per instruction, no LDS round trip.
+__device__ __forceinline__ uint4 record_half(uint2 lo_group, uint2 hi_group) {
+    const auto r0 = __builtin_amdgcn_permlane32_swap(lo_group.x, hi_group.x, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(lo_group.y, hi_group.y, false, false);
+    return make_uint4(r0[0], r1[0], r0[1], r1[1]);
+}
+
+
 // ---- network plan ---------------------------------------------------------
 // Channel counts are padded to multiples of 32 inside the workspace so that
 // every MFMA convolution sees whole 32-wide output tiles and whole 32-byte

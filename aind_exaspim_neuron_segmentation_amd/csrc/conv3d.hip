@@ -181,6 +181,32 @@ __device__ __forceinline__ void store4<F16Tag>(void* dst, size_t off, float a, f
     *reinterpret_cast<f16x4*>(static_cast<_Float16*>(dst) + off) = v;
 }
 
+// the same four channels packed into 8 bytes (16-bit storage types), for stores straight from
+// registers
+template <typename Tag>
+__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d);
+template <>
+__device__ __forceinline__ uint2 pack4<BF16Tag>(float a, float b, float c, float d) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    const bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+    return __builtin_bit_cast(uint2, v);
+}
+template <>
+__device__ __forceinline__ uint2 pack4<F16Tag>(float a, float b, float c, float d) {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    a = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);   // saturating, like store4
+    b = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
+    c = __builtin_amdgcn_fmed3f(c, -65504.f, 65504.f);
+    d = __builtin_amdgcn_fmed3f(d, -65504.f, 65504.f);
+    const f16x4 v = {(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d};
+    return __builtin_bit_cast(uint2, v);
+}
+template <>
+__device__ __forceinline__ uint2 pack4<F32Tag>(float, float, float, float) { return make_uint2(0u, 0u); }   // (unused)
+
+#ifndef EXASPIM_DIRECT_EPILOGUE
+#define EXASPIM_DIRECT_EPILOGUE 1   // 0: every epilogue goes through LDS (measurement aid)
+#endif
 // Phase stamps for tools/conv_trace.hip (compiled out of the library).
 #ifndef EXASPIM_ABLATE
 #define EXASPIM_ABLATE 0   // tools only: 1 = no prefetch loads, 2 = no output stores, 4 = no LDS staging writes
@@ -586,6 +612,34 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
         EXA_TRACE(14);
         return;
     }
+    if (ES == 2 && EXASPIM_DIRECT_EPILOGUE) {
+        // 16-bit types: records assembled with v_permlane32_swap (record_half), no LDS round trip
+        char* const dplane = static_cast<char*>(a.dst) +
+                             ((size_t)nb * (a.cout / KC) + ntile0 * (32 / KC)) * patch_vox * 32;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = (wm * MT + mt) * 32 + r;
+            const int z = m / (TY * TX), y = (m / TX) % TY, x = m % TX;
+            const int gz = z0 + z, gy = y0 + y, gx = x0 + x;
+            const bool ok = m < TILE_VOX && gz < zend && gy < yend && gx < xend;
+            char* const dvox = dplane + (((size_t)gz * a.h + gy) * a.w + gx) * 32 + half * 16;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                uint2 grp[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    grp[q] = pack4<Tag>(leaky(acc[mt][nt][4 * q + 0], a.slope), leaky(acc[mt][nt][4 * q + 1], a.slope),
+                                        leaky(acc[mt][nt][4 * q + 2], a.slope), leaky(acc[mt][nt][4 * q + 3], a.slope));
+#pragma unroll
+                for (int ck = 0; ck < 2; ++ck) {
+                    const uint4 rec = record_half(grp[2 * ck], grp[2 * ck + 1]);
+                    if (ok) *reinterpret_cast<uint4*>(dvox + (size_t)(nt * 2 + ck) * patch_vox * 32) = rec;
+                }
+            }
+        }
+        EXA_TRACE(14);
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -984,6 +1038,30 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
                         a.head_out[(((size_t)cur.nb * HEAD + o) * a.d + gz) * plane + (size_t)gy * a.w + gx] = t;
                 }
             }
+        } else if (ES == 2 && !POOL && EXASPIM_DIRECT_EPILOGUE) {
+            // ---- epilogue: LeakyReLU, records assembled with v_permlane32_swap ------
+            // (16-bit types without the fused max-pool: nothing goes through LDS, so the next
+            // tile's first chunk can be written to the image right behind this)
+            char* const dplane = static_cast<char*>(a.dst) +
+                                 ((size_t)cur.nb * (a.cout / KC) + ntile0 * 2) * patch_vox * 32;
+            const int gy = cur.y0 + pos / TX, gx = cur.x0 + pos % TX;
+            const bool okyx = gy < a.org[1] + a.ext[1] && gx < a.org[2] + a.ext[2];
+            char* const dvox = dplane + ((size_t)gy * a.w + gx) * 32 + half * 16;
+#pragma unroll
+            for (int z = 0; z < TZ; ++z) {
+                uint2 grp[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    grp[q] = pack4<Tag>(leaky(acc[z][4 * q + 0], a.slope), leaky(acc[z][4 * q + 1], a.slope),
+                                        leaky(acc[z][4 * q + 2], a.slope), leaky(acc[z][4 * q + 3], a.slope));
+                const int gz = cur.z0 + z;     // wave-uniform
+#pragma unroll
+                for (int ck = 0; ck < 2; ++ck) {
+                    const uint4 rec = record_half(grp[2 * ck], grp[2 * ck + 1]);
+                    if (okyx && gz < a.org[0] + a.ext[0] && (!(EXASPIM_ABLATE & 2) || rec.x == 0x12345u))
+                        *reinterpret_cast<uint4*>(dvox + ((size_t)ck * patch_vox + (size_t)gz * plane_vox) * 32) = rec;
+                }
+            }
         } else {
             // ---- epilogue: LeakyReLU, transposed through LDS ----------------------
             // One store instruction writes one chunk plane's 32 voxel records (32 B
@@ -1072,7 +1150,8 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
         }
         EXA_TRACE(14);
         if (!has_next) break;
-        if (HEAD == 0) __syncthreads();   // the transposition buffers are free again
+        // the transposition buffers are free again (the direct epilogue never used them)
+        if (HEAD == 0 && !(ES == 2 && !POOL && EXASPIM_DIRECT_EPILOGUE)) __syncthreads();
         stage_store();
         tile_id += t_step;
         cur = nxt;
