@@ -114,14 +114,24 @@ def lib():
     """
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = LIB_PATH
+        # measurement aid (tools/ab_lib.sh): A/B another build of the same ABI without copying it
+        # over the product library; never silent
+        override = os.environ.get("EXASPIM_LIB")
+        if override:
+            import sys
+
+            path = os.path.abspath(override)
+            print(f"exaspim: EXASPIM_LIB is set, loading {path} instead of the in-tree library",
+                  file=sys.stderr)
+        if not os.path.exists(path):
             raise RuntimeError(
-                f"HIP extension not built: {LIB_PATH} is missing. Build it with "
+                f"HIP extension not built: {path} is missing. Build it with "
                 "`make -C aind_exaspim_neuron_segmentation_amd/csrc` (or "
                 "`python -c 'import __graft_entry__ as g; g.build()'`). "
                 "There is no CPU fallback."
             )
-        handle = ctypes.CDLL(LIB_PATH)
+        handle = ctypes.CDLL(path)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype = restype

@@ -103,6 +103,21 @@ __device__ __forceinline__ float leaky(float v, float slope) {
     return r;
 }
 
+// A copy of a value the compiler cannot see through. The persistent z-column kernel sits at its
+// register ceiling; hipcc hoists every lane-derived constant of the per-tile prologue and of the
+// epilogue (LDS addresses of the bias, row / column of the lane, ...) out of the tile loop and
+// then SPILLS them: each came back through a scratch_load whose s_waitcnt vmcnt(0) also waited
+// for the previous tile's output stores and the prefetch in flight (four serialised round trips
+// at every tile top, three in every epilogue). Deriving such values from an opaque copy of the
+// lane index (fresh_lane) inside the loop makes them a few VALU instructions per tile instead.
+// lane index (= threadIdx.x & 63 for the 1-D workgroups here) from the hardware, two VALU
+// instructions without any input register; volatile, so never hoisted and never kept
+__device__ __forceinline__ int fresh_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 // element-wise maximum of two 16-byte channel groups in the storage type (exact: the
 // inputs are already rounded, the larger one is returned bit for bit)
 template <typename Tag>
@@ -204,6 +219,21 @@ __device__ __forceinline__ uint2 pack4<F16Tag>(float a, float b, float c, float 
 template <>
 __device__ __forceinline__ uint2 pack4<F32Tag>(float, float, float, float) { return make_uint2(0u, 0u); }   // (unused)
 
+// Tap loops run at a raised wave priority (s_setprio): a CU holds two workgroups, and while one is in
+// its prologue / staging / epilogue (VALU, LDS writes, stores) the other one's MFMA issue should not
+// queue behind it. Measured inside 512^3 steps (us per launch, two alternating repeats, r03): levels
+// 0 / 1 / 2 / 3 of the z-column kernel: inc.3 803 / 786 / 783 / 785, up4.0 803 / 788 / 788 / 789,
+// up4.3 499 / 486 / 484 / 486, up3.3 171 / 166 / 166 / 166; level 2 in conv3x3x3_t14 as well: the
+// 17 convolutions sum to 4617 instead of 4644 us per batch.
+#ifndef EXASPIM_SETPRIO
+#define EXASPIM_SETPRIO 2   // conv3x3x3_zpipe (0 = off)
+#endif
+#ifndef EXASPIM_SETPRIO_T14
+#define EXASPIM_SETPRIO_T14 2   // conv3x3x3_t14
+#endif
+#ifndef EXASPIM_STAGE_FIRST
+#define EXASPIM_STAGE_FIRST 0   // 1: next tile's first chunk goes to LDS before the epilogue's stores (A/B aid)
+#endif
 #ifndef EXASPIM_DIRECT_EPILOGUE
 #define EXASPIM_DIRECT_EPILOGUE 1   // 0: every epilogue goes through LDS (measurement aid)
 #endif
@@ -465,6 +495,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
         }
 
         const bool more = c + 1 < nchunks;
+        if (EXASPIM_SETPRIO_T14) __builtin_amdgcn_s_setprio(EXASPIM_SETPRIO_T14);
 #pragma unroll
         for (int t = 0; t < 27; ++t) {
             if (t + PD < 27) {
@@ -494,6 +525,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
             // this fence hipcc hoists and sinks them across taps and the loop runs ~20 % slower
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (EXASPIM_SETPRIO_T14) __builtin_amdgcn_s_setprio(0);
         if (more) prime_weights(c + 1);
         if (c - cbeg < 4) EXA_TRACE(3 + 3 * (c - cbeg));
         if (DMA) {
@@ -849,6 +881,7 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
     // where chunk c of patch nb lives: descriptor of the patch of its source, offset of its plane
     struct ChunkSrc {
         __amdgpu_buffer_rsrc_t rsrc;
+        __amdgpu_buffer_rsrc_t none;   // the same with zero records: every load returns zeros
         unsigned cbase;
     };
     auto chunk_src = [&](int c, int nb) {
@@ -860,17 +893,21 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
             src = static_cast<const char*>(a.src_b); cs = a.cb; ch0 = c * KC - a.ca;
         }
         const size_t patchb = patch_vox * cs * ES;  // bytes of one patch of this source
-        return ChunkSrc{make_rsrc(src + (size_t)nb * patchb, patchb),
+        return ChunkSrc{make_rsrc(src + (size_t)nb * patchb, patchb), make_rsrc(src + (size_t)nb * patchb, 0),
                         (unsigned)(ch0 / KC) * (unsigned)patch_vox * 32u};
     };
     // piece i of chunk c of the tile whose first plane is z0: global -> stg[i]
     auto load_piece = [&](const ChunkSrc& cs, int c, int z0, int i) {
         if (i < NITEMS) {
             if (i < HZ) {
+                // A z-halo plane outside the patch is loaded through the zero-record descriptor (the
+                // range check returns zeros) rather than set to zero in a branch: writing the staging
+                // registers there made hipcc wait for EVERY load in flight (s_waitcnt vmcnt(0) in the
+                // middle of the tap loop of every first and last tile of a column).
                 const int gz = z0 + i - 1;  // wave-uniform
                 stg[i] = (unsigned)gz < (unsigned)a.d
                              ? buf_load16(cs.rsrc, p_voff, cs.cbase + (unsigned)gz * plane_vox * 32u)
-                             : make_uint4(0, 0, 0, 0);
+                             : buf_load16(cs.none, p_voff, 0);
             } else {
                 stg[i] = buf_load16(cs.rsrc, s_voff[i - HZ], cs.cbase);
             }
@@ -921,9 +958,10 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
         __syncthreads();   // this tile's first chunk (and, the first time, the bias) is in LDS
         // register 4q+k of a lane is channel 8q + 4*half + k of the slice
         f32x16 acc[TZ];
+        const int half_t = fresh_lane() >> 5;   // (recomputed per tile, see fresh_lane())
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 b = *reinterpret_cast<const float4*>(bias_s + 8 * q + 4 * half);
+            const float4 b = *reinterpret_cast<const float4*>(bias_s + 8 * q + 4 * half_t);
 #pragma unroll
             for (int mt = 0; mt < TZ; ++mt) {
                 acc[mt][4 * q + 0] = b.x; acc[mt][4 * q + 1] = b.y;
@@ -957,6 +995,7 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
             for (int s = 0; s < D; ++s)
                 xr[s % R] = lds[col + (s % HZ) * PLANE + ((s / HZ) / 3) * HXP + (s / HZ) % 3];
             __builtin_amdgcn_sched_barrier(0);
+            if (EXASPIM_SETPRIO) __builtin_amdgcn_s_setprio(EXASPIM_SETPRIO);
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int g = s / HZ, zin = s % HZ;
@@ -983,6 +1022,7 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (EXASPIM_SETPRIO) __builtin_amdgcn_s_setprio(0);
             if (c < 4) EXA_TRACE(3 + 3 * c);
             __syncthreads();   // every wave is done reading this chunk's image
             if (c < 4) EXA_TRACE(4 + 3 * c);
@@ -992,7 +1032,15 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
                 if (c < 3) EXA_TRACE(5 + 3 * c);
             }
         }
+        // epilogues that do not go through LDS leave the image free from here on
+        constexpr bool kLdsFreeEpilogue = HEAD > 0 || (ES == 2 && !POOL && EXASPIM_DIRECT_EPILOGUE);
+        if (EXASPIM_STAGE_FIRST && kLdsFreeEpilogue && has_next) stage_store();
 
+        // the lane's coordinates inside the tile, recomputed per tile (see fresh_lane())
+        const int lane_e = fresh_lane();
+        const int half_e = lane_e >> 5;
+        const int r_e = (TX == 16 && (lane_e & 16)) ? 16 + (((lane_e & 15) - HXP) & 15) : (lane_e & 31);
+        const int pos_e = wave * 32 + r_e;
         if (HEAD > 0) {
             // ---- fused head: OutConv 1x1x1 (+ sigmoid) on the accumulators -----------
             // lane (voxel r, half h) holds channels 8q + 4h + j of its voxel: a 16-term
@@ -1009,7 +1057,7 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
                 float4 hw[HEAD > 0 ? HEAD : 1];
 #pragma unroll
                 for (int o = 0; o < HEAD; ++o)
-                    hw[o] = *reinterpret_cast<const float4*>(head_s + o * 32 + 8 * q + 4 * half);
+                    hw[o] = *reinterpret_cast<const float4*>(head_s + o * 32 + 8 * q + 4 * half_e);
 #pragma unroll
                 for (int z = 0; z < TZ; ++z) {
                     float v0 = acc[z][4 * q + 0], v1 = acc[z][4 * q + 1];
@@ -1024,7 +1072,7 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
                 }
             }
             const size_t plane = (size_t)a.h * a.w;
-            const int gy = cur.y0 + pos / TX, gx = cur.x0 + pos % TX;
+            const int gy = cur.y0 + pos_e / TX, gx = cur.x0 + pos_e % TX;
 #pragma unroll
             for (int z = 0; z < TZ; ++z) {
                 const int gz = cur.z0 + z;
@@ -1034,7 +1082,7 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
                     float t = part[z][o] + __shfl_xor(part[z][o], 32) + head_s[HEAD * 32 + o];
                     if (a.head_sigmoid) t = 1.f / (1.f + expf(-t));
                     // outputs are dealt to the two half-waves so both store
-                    if (ok && (o & 1) == half)
+                    if (ok && (o & 1) == half_e)
                         a.head_out[(((size_t)cur.nb * HEAD + o) * a.d + gz) * plane + (size_t)gy * a.w + gx] = t;
                 }
             }
@@ -1044,9 +1092,9 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
             // tile's first chunk can be written to the image right behind this)
             char* const dplane = static_cast<char*>(a.dst) +
                                  ((size_t)cur.nb * (a.cout / KC) + ntile0 * 2) * patch_vox * 32;
-            const int gy = cur.y0 + pos / TX, gx = cur.x0 + pos % TX;
+            const int gy = cur.y0 + pos_e / TX, gx = cur.x0 + pos_e % TX;
             const bool okyx = gy < a.org[1] + a.ext[1] && gx < a.org[2] + a.ext[2];
-            char* const dvox = dplane + ((size_t)gy * a.w + gx) * 32 + half * 16;
+            char* const dvox = dplane + ((size_t)gy * a.w + gx) * 32 + half_e * 16;
 #pragma unroll
             for (int z = 0; z < TZ; ++z) {
                 uint2 grp[4];
@@ -1077,7 +1125,7 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
             char* wl = reinterpret_cast<char*>(lds) + wave * (TB * 32 * RECP);
             char* const dplane = static_cast<char*>(a.dst) +
                                  ((size_t)cur.nb * (a.cout / KC) + ntile0 * CPT) * patch_vox * 32;
-            const int vv = lane >> 1, sub = lane & 1;
+            const int vv = lane_e >> 1, sub = lane_e & 1;
             const int po = wave * 32 + vv;
             const int ogy = cur.y0 + po / TX, ogx = cur.x0 + po % TX;
 #pragma unroll
@@ -1086,7 +1134,7 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
                 for (int z = zb; z < zb + TB && z < TZ; ++z) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int cl = 8 * q + 4 * half;
+                        const int cl = 8 * q + 4 * half_e;
                         // LeakyReLU with 0 <= slope <= 1 is max(v, slope * v)
                         float v0 = acc[z][4 * q + 0], v1 = acc[z][4 * q + 1];
                         float v2 = acc[z][4 * q + 2], v3 = acc[z][4 * q + 3];
@@ -1094,7 +1142,7 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
                         v1 = leaky(v1, a.slope);
                         v2 = leaky(v2, a.slope);
                         v3 = leaky(v3, a.slope);
-                        store4<Tag>(wl + (z - zb) * (32 * RECP), (size_t)(r * RECP) / ES + cl, v0, v1, v2, v3);
+                        store4<Tag>(wl + (z - zb) * (32 * RECP), (size_t)(r_e * RECP) / ES + cl, v0, v1, v2, v3);
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1123,7 +1171,7 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
                                          ((size_t)cur.nb * (a.cout / KC) + ntile0 * CPT) * pvox * 32;
 #pragma unroll
                     for (int p0 = 0; p0 < NP; p0 += 64) {
-                        const int p = p0 + lane;
+                        const int p = p0 + lane_e;
                         const int zp = p / (8 * CPT * 2), rem = p % (8 * CPT * 2);
                         const int ck = rem / 16, xp = (rem % 16) >> 1, sb = rem & 1;
                         if (p < NP && zb + 2 * zp + 1 < TZ) {
@@ -1151,8 +1199,8 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
         EXA_TRACE(14);
         if (!has_next) break;
         // the transposition buffers are free again (the direct epilogue never used them)
-        if (HEAD == 0 && !(ES == 2 && !POOL && EXASPIM_DIRECT_EPILOGUE)) __syncthreads();
-        stage_store();
+        if (!kLdsFreeEpilogue) __syncthreads();
+        if (!(EXASPIM_STAGE_FIRST && kLdsFreeEpilogue)) stage_store();
         tile_id += t_step;
         cur = nxt;
     }

@@ -26,6 +26,7 @@ There is no CPU fallback: a model on a CPU device raises.
 
 import itertools
 import os
+import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
 
@@ -40,6 +41,12 @@ try:  # progress bar is cosmetic; the reference imports tqdm unconditionally
     from tqdm import tqdm
 except ImportError:  # pragma: no cover
     tqdm = None
+
+# Batches in flight on separate HIP streams in predict() / predict_streaming(): measured on MI355X
+# (1024^3, fp16, batch 16) three are 5 % faster than one -- one kernel's last, partly idle round of
+# workgroups overlaps another batch's work -- and the result does not change by a bit (stitching
+# stays in batch order on the caller's stream).
+DEFAULT_STREAMS = 3
 
 _VOX_CODES = {
     np.dtype(np.uint8): _native.VOX_U8,
@@ -63,7 +70,7 @@ def predict(
     verbose=True,
     *,
     return_device_tensor=False,
-    n_streams=1,
+    n_streams=DEFAULT_STREAMS,
     out_dtype=np.float32,
 ):
     """
@@ -106,7 +113,7 @@ def predict(
         compute (see predict_streaming).
     n_streams : int, optional
         Batches in flight on separate HIP streams (see run_sliding_window);
-        the result does not depend on it. Default is 1.
+        the result does not depend on it. Default is 3 (DEFAULT_STREAMS).
     out_dtype : numpy.dtype, optional
         numpy.float32 (default, the reference's) or numpy.float16: the
         finished result rounded to IEEE half on the device (round to nearest
@@ -718,11 +725,13 @@ def run_sliding_window(volume, model, plan, n_channels, batch_size, brightness_c
         Batches in flight: gather + network of consecutive batches alternate
         between this many HIP streams (each with its own workspace); the stitch
         kernels stay on the caller's stream in batch order, so results do not
-        depend on this number. Measured on MI355X (1024^3, bf16, batch 16): three
-        streams are 7 % faster than one because the ramp-down of one kernel
-        overlaps the next batch's work, but kernels of different batches then
-        share the device and per-kernel timings lose their meaning, so the
-        default is 1. Moving only gather/stitch to a side stream gains nothing.
+        depend on this number. Measured on MI355X (1024^3, 16-bit, batch 16): three
+        streams are 5-7 % faster than one because the ramp-down of one kernel
+        overlaps the next batch's work, which is why predict() asks for three;
+        kernels of different batches then share the device and per-kernel
+        timings lose their meaning, so this building block (and bench.py's
+        roofline leg) defaults to 1. Moving only gather/stitch to a side stream
+        gains nothing.
     starts : List[Tuple[int]], optional
         Patch starts to process (default: all of plan.starts()).
     accum : torch.Tensor, optional
@@ -801,28 +810,136 @@ def run_sliding_window(volume, model, plan, n_channels, batch_size, brightness_c
 
 
 # --- slab pipeline: out-of-core input, overlapped transfers ---
-_PINNED = {}
 _COPY_STREAMS = {}
+_PINNED_LOCK = threading.Lock()
+_PINNED_FREE = {}               # (device, torch dtype) -> page-locked buffers no call is using
+PINNED_SLOT_BYTES = 512 << 20   # a finished slab is cut so that one staging slot stays below this
 
 
-def _pinned_buffers(tag, count, numel, dtype):
-    """Page-locked staging buffers, kept between calls (they never leave this
-    module: results are copied out of them before a call returns)."""
-    pool = _PINNED.setdefault((tag, dtype), [])
-    while len(pool) < count:
-        pool.append(None)
-    for i in range(count):
-        if pool[i] is None or pool[i].numel() < numel:
-            pool[i] = torch.empty(numel, dtype=dtype, pin_memory=True)
-    return pool[:count]
+def _checkout_pinned(device, count, numel, dtype):
+    """
+    Takes "count" host staging buffers of at least "numel" elements out of the pool of the
+    device (page-locked, kept between calls so that a second predict() does not pay for
+    hipHostMalloc again). A buffer belongs to ONE call from here until _return_pinned:
+    concurrent predict() calls -- threads driving different GPUs, or the same one -- never
+    share staging memory. If the runtime refuses to page-lock more memory the buffer is
+    ordinary pageable memory (the download then blocks the copy stream, nothing else changes).
+    """
+    key = (str(device), dtype)
+    with _PINNED_LOCK:
+        free = _PINNED_FREE.setdefault(key, [])
+        free.sort(key=lambda t: t.numel())
+        taken = []
+        while free and len(taken) < count and free[-1].numel() >= numel:
+            taken.append(free.pop())
+    while len(taken) < count:
+        try:
+            taken.append(torch.empty(numel, dtype=dtype, pin_memory=True))
+        except RuntimeError:
+            taken.append(torch.empty(numel, dtype=dtype))
+    return taken
+
+
+def _return_pinned(device, dtype, buffers):
+    """Hands staging buffers back to the device's pool (pageable fall-backs are dropped)."""
+    with _PINNED_LOCK:
+        _PINNED_FREE.setdefault((str(device), dtype), []).extend(b for b in buffers if b.is_pinned())
+
+
+def release_pinned_buffers():
+    """Frees the page-locked staging buffers predict() keeps between calls."""
+    with _PINNED_LOCK:
+        _PINNED_FREE.clear()
 
 
 def _copy_stream(device):
     """The stream the slab downloads run on (one per device, created once)."""
     key = str(device)
-    if key not in _COPY_STREAMS:
-        _COPY_STREAMS[key] = torch.cuda.Stream(device)
-    return _COPY_STREAMS[key]
+    with _PINNED_LOCK:
+        if key not in _COPY_STREAMS:
+            _COPY_STREAMS[key] = torch.cuda.Stream(device)
+        return _COPY_STREAMS[key]
+
+
+class _SlabDrain:
+    """
+    Moves finished output slabs off the device while later patch layers compute: a slab is
+    written (and divided) into one of three device slots on the caller's stream, downloaded to
+    a host staging slot on the copy stream, and handed to host threads from there.
+
+    Parameters
+    ----------
+    device : torch.device
+        The HIP device.
+    slot_elems : int
+        Elements of the largest slab handed to emit().
+    half_out : bool
+        Round slabs to IEEE half on the device before they leave it.
+    threads : int
+        Host threads that consume downloaded slabs.
+    """
+
+    N_SLOTS = 3
+
+    def __init__(self, device, slot_elems, half_out, threads):
+        self.device = device
+        self.half_out = half_out
+        self.main = torch.cuda.current_stream(device)
+        self.copy_stream = _copy_stream(device)
+        self.host_dtype = torch.float16 if half_out else torch.float32
+        n = self.N_SLOTS
+        self.dev_out = [torch.empty(slot_elems, dtype=torch.float32, device=device) for _ in range(n)]
+        self.dev_half = ([torch.empty(slot_elems, dtype=torch.float16, device=device) for _ in range(n)]
+                         if half_out else None)
+        self.host = _checkout_pinned(device, n, slot_elems, self.host_dtype)
+        self.pool = ThreadPoolExecutor(max_workers=max(1, int(threads)))
+        self.pending = [[] for _ in range(n)]
+        self.n_emitted = 0
+
+    def emit(self, shape, fill, consumers):
+        """
+        Queues one slab: "fill(out)" writes the final values into the zeroed float32 device
+        tensor "out" of "shape"; "consumers(view)" returns the host jobs (callables) that read
+        the downloaded numpy "view" of the same shape -- each runs on a pool thread once the
+        download has finished, and the staging slot is reused only after all of them returned.
+        """
+        slot = self.n_emitted % self.N_SLOTS
+        self.n_emitted += 1
+        for f in self.pending[slot]:
+            f.result()                   # the slot's previous slab has left the staging memory
+        count = int(np.prod(shape))
+        out = self.dev_out[slot][:count].view(shape)
+        out.zero_()                      # planes no patch covers stay 0 (inference.py:120-125)
+        fill(out)
+        if self.half_out:
+            out = export_half(out, self.dev_half[slot][:count]).view(shape)
+        ready, done = torch.cuda.Event(), torch.cuda.Event()
+        ready.record(self.main)
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(ready)
+            self.host[slot][:count].view(shape).copy_(out, non_blocking=True)
+            done.record(self.copy_stream)
+        view = self.host[slot][:count].numpy().reshape(shape)
+
+        def after_download(job):
+            def run():
+                done.synchronize()
+                job()
+            return run
+
+        self.pending[slot] = [self.pool.submit(after_download(job)) for job in consumers(view)]
+
+    def drain(self):
+        """Waits until every queued slab has been consumed (re-raises a consumer's exception)."""
+        for jobs in self.pending:
+            for f in jobs:
+                f.result()
+        self.pending = [[] for _ in range(self.N_SLOTS)]
+
+    def close(self):
+        self.pool.shutdown(wait=True)
+        _return_pinned(self.device, self.host_dtype, self.host)
+        self.host = []
 
 
 class _ArraySource:
@@ -893,7 +1010,7 @@ def predict_streaming(
     dtype=None,
     write_block=None,
     keep_input_resident=None,
-    n_streams=1,
+    n_streams=DEFAULT_STREAMS,
     copy_threads=4,
     timings=None,
     out_dtype=np.float32,
@@ -1007,8 +1124,6 @@ def predict_streaming(
         return _carrier(convert(block))
 
     with torch.cuda.device(device):
-        main = torch.cuda.current_stream(device)
-        copy_stream = _copy_stream(device)
         plane_bytes = plane * vdtype.itemsize
         if keep_input_resident is None:
             free, _ = torch.cuda.mem_get_info(device)
@@ -1049,28 +1164,18 @@ def predict_streaming(
         band = pz - 2 * plan.trim - stride          # partial sums the next layer continues
         slab_d = min(pz, D)
         # deepest slab handed over at once: a layer finishes stride planes (the first one
-        # stride + trim, the last one the patch depth - trim); anything deeper is cut
-        max_out = min(D, max(stride + plan.trim, pz))
-        n_slots = 3
-        dev_out = [torch.empty(n_channels * max_out * plane, dtype=torch.float32, device=device)
-                   for _ in range(n_slots)]
-        out_torch = torch.float16 if half_out else torch.float32
-        pinned = _pinned_buffers("out16" if half_out else "out", n_slots, n_channels * max_out * plane,
-                                 out_torch)
-        dev_half = None
-        if half_out:
-            dev_half = [torch.empty(n_channels * max_out * plane, dtype=torch.float16, device=device)
-                        for _ in range(n_slots)]
+        # stride + trim, the last one the patch depth - trim); anything deeper is cut, and so is
+        # anything that would make a staging slot larger than PINNED_SLOT_BYTES
+        max_out = min(D, max(stride + plan.trim, pz), max(1, PINNED_SLOT_BYTES // (n_channels * plane * 4)))
+        # a sink is called from ONE thread, so the slabs arrive in z order, one at a time;
+        # copies into the result array are split over several threads
+        drain = _SlabDrain(device, n_channels * max_out * plane, half_out,
+                           1 if write_block is not None else max(1, int(copy_threads)))
         acc_flat = [torch.empty(n_channels * slab_d * plane, dtype=torch.float32, device=device)
                     for _ in range(2)]
         in_slab = None
         if resident is None:
             in_slab = [torch.empty((slab_d, H, W), dtype=torch_dtype, device=device) for _ in range(2)]
-        # a sink is called from ONE thread, so the slabs arrive in z order, one at a time;
-        # copies into the result array are split over several threads
-        pool = ThreadPoolExecutor(max_workers=1 if write_block is not None else max(1, int(copy_threads)))
-        pending = [[] for _ in range(n_slots)]
-        n_emitted = 0
         pbar = None
         if verbose and tqdm is not None:
             pbar = tqdm(total=len(z_starts) * len(yx_starts), desc="Predict")
@@ -1080,49 +1185,25 @@ def predict_streaming(
             depth = min(zs + pz, D) - zs
             return acc_flat[k % 2][: n_channels * depth * plane].view(n_channels, depth, H, W)
 
-        def hand_over(slot, z0, z1, done):
-            """pinned[slot] holds output planes [z0, z1) once the event "done" has fired."""
-            view = pinned[slot][: n_channels * (z1 - z0) * plane].numpy().reshape(
-                n_channels, z1 - z0, H, W)
-            if write_block is not None:
-                def job():
-                    done.synchronize()
-                    write_block(z0, z1, view if affinity_mode else view[0])
-                return [pool.submit(job)]
-            # the copy into the pageable result is split over the threads
-            pieces = max(1, min(int(copy_threads), z1 - z0))
-            jobs = []
-            for i in range(pieces):
-                a = z0 + (z1 - z0) * i // pieces
-                b = z0 + (z1 - z0) * (i + 1) // pieces
-
-                def job(a=a, b=b):
-                    done.synchronize()
-                    np.copyto(res4[:, a:b], view[:, a - z0:b - z0])
-                jobs.append(pool.submit(job))
-            return jobs
+        def consumers(z0, z1):
+            """Host jobs for output planes [z0, z1) once they sit in staging memory."""
+            def make(view):
+                if write_block is not None:
+                    return [lambda: write_block(z0, z1, view if affinity_mode else view[0])]
+                # the copy into the pageable result is split over the threads
+                pieces = max(1, min(int(copy_threads), z1 - z0))
+                jobs = []
+                for i in range(pieces):
+                    a = z0 + (z1 - z0) * i // pieces
+                    b = z0 + (z1 - z0) * (i + 1) // pieces
+                    jobs.append(lambda a=a, b=b: np.copyto(res4[:, a:b], view[:, a - z0:b - z0]))
+                return jobs
+            return make
 
         def emit(z0, z1, fill):
             """Planes [z0, z1) are final: "fill(out)" writes the divided sums into the
             zeroed (C, z1 - z0, H, W) device slab, which then travels to the host."""
-            nonlocal n_emitted
-            slot = n_emitted % n_slots
-            n_emitted += 1
-            for f in pending[slot]:
-                f.result()                   # the slot's previous slab has left pinned memory
-            count = n_channels * (z1 - z0) * plane
-            out = dev_out[slot][:count].view(n_channels, z1 - z0, H, W)
-            out.zero_()                      # planes no patch covers stay 0 (inference.py:120-125)
-            fill(out)
-            if half_out:
-                out = export_half(out, dev_half[slot][:count]).view(out.shape)
-            ready, done = torch.cuda.Event(), torch.cuda.Event()
-            ready.record(main)
-            with torch.cuda.stream(copy_stream):
-                copy_stream.wait_event(ready)
-                pinned[slot][:count].view(out.shape).copy_(out, non_blocking=True)
-                done.record(copy_stream)
-            pending[slot] = hand_over(slot, z0, z1, done)
+            drain.emit((n_channels, z1 - z0, H, W), fill, consumers(z0, z1))
 
         try:
             final_lo = 0
@@ -1175,13 +1256,11 @@ def predict_streaming(
                 torch.cuda.synchronize(device)
                 timings["layers"] = time.perf_counter() - t_phase
                 t_phase = time.perf_counter()
-            for jobs in pending:
-                for f in jobs:
-                    f.result()
+            drain.drain()
             if timings is not None:
                 timings["drain"] = time.perf_counter() - t_phase
         finally:
-            pool.shutdown(wait=True)
+            drain.close()
             if pbar is not None:
                 pbar.close()
     return result

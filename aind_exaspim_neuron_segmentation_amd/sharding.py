@@ -319,9 +319,26 @@ def exchange_input_halo(core, shard, group):
     return block
 
 
+def _timed(timings, key, device, fn):
+    """Runs fn(); with a timings dict, between device synchronisations, adding the wall
+    seconds to timings[key] and to timings["seconds"] (the total of all exchange steps)."""
+    import time
+
+    if timings is None:
+        return fn()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    out = fn()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    timings[key] = timings.get(key, 0.0) + dt
+    timings["seconds"] = timings.get("seconds", 0.0) + dt
+    return out
+
+
 def predict_shard(volume, model, plan, shard, n_channels=3, batch_size=16,
                   brightness_clip=1000, normalization_percentiles=(1, 99.9), group=None,
-                  n_streams=1, timings=None):
+                  n_streams=1, timings=None, core=None):
     """
     Runs one rank's share of predict() on its device: global percentiles
     (histogram all-reduce), the rank's patches, the band exchange and the final
@@ -341,39 +358,38 @@ def predict_shard(volume, model, plan, shard, n_channels=3, batch_size=16,
     group : ProcessGroup, optional
         Process group (None = single process).
     timings : dict, optional
-        If given, timings["seconds"] is increased by the wall time this rank
-        spends in the two exchange steps (histogram all-reduce, output bands),
-        measured between device synchronisations.
+        If given, the wall time this rank spends in the exchange steps, measured
+        between device synchronisations, is added to timings["histogram_s"] (the
+        all-reduce of the percentile histograms), timings["output_bands_s"] and
+        their total timings["seconds"].
+    core : torch.Tensor, optional
+        The rank's disjoint sub-volume (shard.core_dims, contiguous, on the
+        device) when the caller holds it anyway (it fed exchange_input_halo):
+        the histogram then runs over it instead of over a copy cut out of
+        "volume".
     """
-    import time
-
     from aind_exaspim_neuron_segmentation_amd import inference
 
     device = volume.tensor.device
     multi = group is not None and shard.grid[0] * shard.grid[1] > 1
     if multi:
-        import torch.distributed as dist
-
-        core_sl = shard.local(
-            shard.core_origin,
-            tuple(o + d for o, d in zip(shard.core_origin, shard.core_dims)),
-            shard.input_origin,
-        )
-        core = inference.DeviceVolume(
-            volume.tensor[core_sl].contiguous(), volume.np_dtype, shard.core_origin, plan.shape,
-            storage_dtype=volume.storage_dtype,
+        if core is None:
+            core_sl = shard.local(
+                shard.core_origin,
+                tuple(o + d for o, d in zip(shard.core_origin, shard.core_dims)),
+                shard.input_origin,
+            )
+            core = volume.tensor[core_sl].contiguous()
+        elif tuple(core.shape) != tuple(shard.core_dims):
+            raise ValueError(f"core has shape {tuple(core.shape)}, expected {tuple(shard.core_dims)}")
+        core_vol = inference.DeviceVolume(
+            core, volume.np_dtype, shard.core_origin, plan.shape, storage_dtype=volume.storage_dtype,
         )
 
         def reduce_fn(hist):
-            if timings is not None:
-                torch.cuda.synchronize(device)
-                t0 = time.perf_counter()
-            all_reduce_sum(hist, group)
-            if timings is not None:
-                torch.cuda.synchronize(device)
-                timings["seconds"] = timings.get("seconds", 0.0) + time.perf_counter() - t0
+            _timed(timings, "histogram_s", device, lambda: all_reduce_sum(hist, group))
 
-        mn, mx = inference.volume_percentiles(core, brightness_clip, normalization_percentiles,
+        mn, mx = inference.volume_percentiles(core_vol, brightness_clip, normalization_percentiles,
                                               reduce_fn=reduce_fn)
     else:
         mn, mx = inference.volume_percentiles(volume, brightness_clip, normalization_percentiles)
@@ -384,13 +400,7 @@ def predict_shard(volume, model, plan, shard, n_channels=3, batch_size=16,
         starts=shard.starts, accum_block=accum_block, n_streams=n_streams,
     )
     if multi:
-        if timings is not None:
-            torch.cuda.synchronize(device)
-            t0 = time.perf_counter()
-        exchange_output_bands(accum, shard, group)
-        if timings is not None:
-            torch.cuda.synchronize(device)
-            timings["seconds"] = timings.get("seconds", 0.0) + time.perf_counter() - t0
+        _timed(timings, "output_bands_s", device, lambda: exchange_output_bands(accum, shard, group))
     inference.stitch_finalize(accum, plan, accum_block)
     return accum
 

@@ -56,10 +56,11 @@ def is_contained(voxel, shape, buffer=0):
     Returns
     -------
     bool
-        True if voxel - buffer and voxel + buffer lie inside the volume on
-        every axis.
+        True if voxel - buffer and voxel + buffer both lie inside [0, size) on
+        every axis (two-sided on both, so a negative buffer is handled like the
+        reference handles it).
     """
-    return all(0 <= v - buffer and v + buffer < s for v, s in zip(voxel, shape))
+    return all(0 <= v + buffer < s and 0 <= v - buffer < s for v, s in zip(voxel, shape))
 
 
 def reflect_index(j, n):

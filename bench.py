@@ -35,9 +35,17 @@ block); bf16 storage runs at the same speed but sits at 2.3e-3 .. 2.9e-3.
 Rank 0 prints ONE JSON line with the contract fields plus "roofline" (dominant
 kernel, HIP-event timed on the launch stream), "parity" (this dtype against the
 reference's own 160^3 output, tests/golden/g6), "pipelined" (the same steps with
-three batches in flight on separate HIP streams: faster, but kernels overlap, so it
-is reported beside `value`, never as it), "host_to_host" and
+three batches in flight on separate HIP streams -- what predict() does by default:
+faster, but kernels overlap, so it is reported beside `value`, never as it),
+"host_to_host", "configs" (at N = 1 the other single-GPU configurations of
+BASELINE.json: configs[1] = 512^3, batch 8, fp32, and configs[2] in its literal
+bf16 wording, each with value, dominant-kernel fraction and parity) and
 "cpu_baseline" (the CPU oracle timed on this host's cores on a bounded sample).
+
+N > 1: every rank synthesises only its DISJOINT sub-volume and fetches the halo its
+last patches read from the +z / +y / +z+y neighbours inside the timed step
+(--input-halo exchange, the default; "synth" synthesises the halo in place);
+config.exchange_ms is split into histogram_ms / input_halo_ms / output_bands_ms.
 """
 
 import argparse
@@ -60,6 +68,7 @@ PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense MFMA, MI3
 DOMINANT_CONVS = [(14, 64, 32, 48), (15, 64, 32, 96)]  # up3.3, up4.0
 TRIM = 8  # predict()'s default (inference.py:38)
 TIMER_RING = 16384  # launches the engine's event ring holds (csrc/engine.hip)
+PROFILE_ROUND = "r03"  # profiles/<round>_pmc_hbm_<dtype>.json of the code this file measures
 # (z, y, x) extents in units of --size per world size: BASELINE.json configs[2], [3], -, [4]
 GLOBAL_SHAPES = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (4, 2, 2)}
 CONFIG_NAMES = {1: "configs[2]", 2: "configs[3]", 8: "configs[4]"}
@@ -81,7 +90,12 @@ def parse_args():
                         "the device, so the per-kernel roofline timing means what it says)")
     p.add_argument("--pipelined-streams", type=int, default=3,
                    help="batches in flight of the extra 'pipelined' measurement (0 = skip it)")
-    p.add_argument("--cpu-sample", type=int, default=160, help="edge of the CPU sample volume")
+    p.add_argument("--cpu-sample", type=int, default=224, help="edge of the CPU sample volume")
+    p.add_argument("--cpu-batch", type=int, default=16, help="batch size of the CPU sample run")
+    p.add_argument("--no-configs", action="store_true", help="skip the extra single-GPU config legs")
+    p.add_argument("--input-halo", default=None, choices=["exchange", "synth"],
+                   help="N > 1: fetch the input halo from the neighbours inside the timed step "
+                        "(exchange, default) or synthesise every rank's halo in place (synth)")
     return p.parse_args()
 
 
@@ -93,7 +107,9 @@ def zcol_main(ext, tile):
 
 
 def launch_ranks(args):
-    """Parent of an N-rank run: spawns the ranks and never initialises the GPU."""
+    """Parent of an N-rank run: spawns the ranks and never initialises the GPU. The children are
+    polled; the first one that exits non-zero takes the others down with it (they would otherwise
+    sit in a collective waiting for the dead rank) and the parent exits non-zero."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -102,13 +118,29 @@ def launch_ranks(args):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    codes = [p.wait() for p in procs]
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    bad = []
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad or all(c == 0 for c in codes):
+                break
+            time.sleep(0.2)
+    finally:
+        live = [p for p in procs if p.poll() is None]     # exactly the children started above
+        for p in live:
+            p.terminate()
+        for p in live:
+            try:
+                p.wait(timeout=15)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
     if bad:
-        raise SystemExit(f"bench.py: ranks failed (rank, exit code): {bad}")
+        raise SystemExit(f"bench.py: ranks failed (rank, exit code): {bad}; the other ranks were stopped")
 
 
-def cpu_baseline(sample_edge, full_edge):
+def cpu_baseline(sample_edge, full_edge, batch):
     """Times the CPU oracle (torch CPU fp32, all host cores) on a bounded sample."""
     import numpy as np
     import torch
@@ -121,7 +153,7 @@ def cpu_baseline(sample_edge, full_edge):
     vol = synthetic.synth_volume((sample_edge,) * 3, seed=0)
     n_patches = oracle.count_patches((1, 1) + vol.shape, (96,) * 3, (32,) * 3)
     t0 = time.perf_counter()
-    oracle.predict(vol, model, batch_size=8)
+    oracle.predict(vol, model, batch_size=batch)
     dt = time.perf_counter() - t0
     full_patches = oracle.count_patches((1, 1, full_edge, full_edge, full_edge), (96,) * 3, (32,) * 3)
     t_pre0 = time.perf_counter()
@@ -134,9 +166,9 @@ def cpu_baseline(sample_edge, full_edge):
         "cores": torch.get_num_threads(),
         "kind": "port",
         "sample": (
-            f"oracle predict() on {sample_edge}^3 ({n_patches} patches, batch 8) took {dt:.1f} s "
-            f"= {dt / n_patches:.2f} s/patch; extrapolated to {full_edge}^3 = {full_patches} patches "
-            f"+ {t_pre:.0f} s normalise (scaled from 256^3); os.cpu_count()={os.cpu_count()}"
+            f"oracle predict() on {sample_edge}^3 ({n_patches} patches, batch {batch}) took {dt:.1f} s "
+            f"= {dt / n_patches:.2f} s/patch (measured); extrapolated to {full_edge}^3 = {full_patches} patches "
+            f"+ {t_pre:.0f} s normalise (scaled from a measured 256^3); os.cpu_count()={os.cpu_count()}"
         ),
     }
 
@@ -168,55 +200,200 @@ def parity_block(model, dtype):
 
 
 def host_to_host(model, args, edge):
-    """predict() from a host numpy array to a host numpy array on the N = 1 workload."""
+    """predict() from a host numpy array to a host numpy array on the N = 1 workload, with
+    predict()'s own defaults (three batches in flight) and, beside it, on a single stream."""
     import numpy as np
     import torch
 
-    from aind_exaspim_neuron_segmentation_amd import _native, inference
+    from aind_exaspim_neuron_segmentation_amd import inference
 
     dev = next(model.parameters()).device
-    vol_t = torch.empty((edge,) * 3, dtype=torch.int16, device=dev)
-    blk = _native.Block.make((edge,) * 3, (0, 0, 0), (edge,) * 3)
-    _native.check(_native.lib().exaspim_synth_volume_u16(vol_t.data_ptr(), blk, 0, None), "synth")
-    vol = vol_t.cpu().numpy().view(np.uint16)
-    del vol_t
+    vol = synth_block((0, 0, 0), (edge,) * 3, (edge,) * 3, dev).cpu().numpy().view(np.uint16)
+    torch.cuda.empty_cache()
     times = []
     out = None
     for _ in range(3):          # the first call also page-locks the staging buffers
         del out                 # (unmapping the previous 12 B/voxel result is not part of a call)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        out = inference.predict(vol, model, batch_size=args.batch, verbose=False, n_streams=args.streams)
+        out = inference.predict(vol, model, batch_size=args.batch, verbose=False)
         times.append(time.perf_counter() - t0)
     dt = min(times[1:])
+    checksum = float(out[:, ::7, ::7, ::7].sum(dtype=np.float64))
     phases = {}
-    inference.predict_streaming(vol, model, batch_size=args.batch, verbose=False, n_streams=args.streams,
-                                timings=phases)
-    piped = None
-    if args.pipelined_streams > 1 and args.streams == 1:
-        # the same call with predict()'s n_streams option (bit-identical result)
-        ptimes = []
+    inference.predict_streaming(vol, model, batch_size=args.batch, verbose=False, timings=phases)
+    single = None
+    if args.pipelined_streams > 1:
+        # the same call on one stream (bit-identical result)
+        stimes = []
         for _ in range(2):
             del out
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            out = inference.predict(vol, model, batch_size=args.batch, verbose=False,
-                                    n_streams=args.pipelined_streams)
-            ptimes.append(time.perf_counter() - t0)
-        piped = {"streams": args.pipelined_streams, "value": float(edge) ** 3 / min(ptimes),
-                 "ms_per_step": min(ptimes) * 1e3}
+            out = inference.predict(vol, model, batch_size=args.batch, verbose=False, n_streams=1)
+            stimes.append(time.perf_counter() - t0)
+        single = {"streams": 1, "value": float(edge) ** 3 / min(stimes), "ms_per_step": min(stimes) * 1e3,
+                  "output_checksum": float(out[:, ::7, ::7, ::7].sum(dtype=np.float64))}
     return {
         "phases_s": {k: round(v, 4) for k, v in phases.items()},
         "value": float(edge) ** 3 / dt,
         "unit": "voxels/s",
         "ms_per_step": dt * 1e3,
-        "pipelined": piped,
+        "streams": inference.DEFAULT_STREAMS,
+        "single_stream": single,
         "first_call_ms": times[0] * 1e3,
-        "what": "inference.predict(numpy uint16 -> numpy float32 (3, D, H, W)): chunked upload + "
-                "histogram, finished 64-plane slabs downloaded to pinned memory on a copy stream and "
+        "what": "inference.predict(numpy uint16 -> numpy float32 (3, D, H, W)) with its defaults: chunked "
+                "upload + histogram, finished slabs downloaded to pinned memory on a copy stream and "
                 "moved into the pageable result by 4 host threads while later layers compute",
-        "output_checksum": float(out[:, ::7, ::7, ::7].sum(dtype=np.float64)),
+        "output_checksum": checksum,
     }
+
+
+def make_model(dtype, device):
+    """Random-init weights of the reference architecture (no checkpoints offline)."""
+    import torch
+
+    from aind_exaspim_neuron_segmentation_amd.machine_learning.unet3d import UNet3D
+    from aind_exaspim_neuron_segmentation_amd.utils import synthetic
+
+    sd = synthetic.synth_state_dict(3, 1, seed=1)
+    model = UNet3D(output_channels=3, compute_dtype=dtype)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model.to(device).eval()
+    with torch.cuda.device(device):
+        model._ensure_engine(device)  # pack + upload weights before anything is timed
+    return model
+
+
+def synth_block(origin, dims, gshape, device):
+    """uint16 block [origin, origin + dims) of the synthetic global volume, generated on the device."""
+    import torch
+
+    from aind_exaspim_neuron_segmentation_amd import _native
+
+    t = torch.empty(tuple(dims), dtype=torch.int16, device=device)
+    blk = _native.Block.make(tuple(dims), tuple(origin), tuple(gshape))
+    _native.check(_native.lib().exaspim_synth_volume_u16(t.data_ptr(), blk, 0, None), "synth")
+    return t
+
+
+def dominant_roofline(ms, cnt, dtype, batch, patches_per_step):
+    """Roofline block of the dominant kernel symbol from the engine's event timers (the 32-cout
+    MFMA convolution: up3.3 and up4.0 are the same instantiation, so rocprofv3's per-kernel
+    average covers exactly these launches)."""
+    launches = sum(cnt[b] for b, _, _, _ in DOMINANT_CONVS)
+    k_ms = sum(ms[b] for b, _, _, _ in DOMINANT_CONVS)
+    flops = 0.0
+    for b, cin, cout, edge in DOMINANT_CONVS:
+        # up4.0 (bit 15) only computes what up4.3 reads of the voxels predict() keeps:
+        # trim - 1 voxels less on every face (exaspim_unet_forward_trimmed) = 82^3; of
+        # that the timed z-column launch covers the whole 8 x 16 (y, x) tiles, 82 x 80 x 80
+        # (the two 2-voxel-thick remainders run as separate, untimed thin-tile launches)
+        need = edge - 2 * (TRIM - 1) if b == 15 else edge
+        vox = need * zcol_main(need, 8) * zcol_main(need, 16) if b == 15 else need ** 3
+        flops += cnt[b] * 2.0 * 27 * cin * cout * batch * vox
+    # the last batch of a step may be short; scale by the real patch count
+    full_batches = -(-patches_per_step // batch)
+    flops *= patches_per_step / float(full_batches * batch)
+    achieved = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+    peak = PEAK_TFLOPS[dtype]
+    launches_per_step = len(DOMINANT_CONVS) * full_batches
+    tag = {"bf16": "BF16Tag", "fp16": "F16Tag", "fp32": "F32Tag"}[dtype]
+    # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes of THIS
+    # round's code (FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md says;
+    # profiles/summarize.py); null when no such pass exists for this dtype.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_hbm_{dtype}.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            entry = json.load(f).get("kernels", {}).get(f"conv3x3x3_zpipe<{tag}, 6, 8, 16, 2, 4, 0, false>")
+        if entry:
+            traffic = entry["hbm_bytes_per_launch"]
+    return {
+        "bound": "mfma",
+        "kernel": f"conv3x3x3_zpipe<{tag}, tile 6x8x16, 32 couts, no head, no pool> (launches: up3.3, up4.0)",
+        "algorithmic_flop_per_launch": flops / launches if launches else None,
+        "achieved": achieved,
+        "peak": peak,
+        "unit": "TFLOP/s",
+        "frac": achieved / peak,
+        "avg_launch_ms": k_ms / launches if launches else None,
+        "timed_launches": launches,
+        "steps_covered": launches / float(launches_per_step) if launches_per_step else None,
+        "timer_ring": TIMER_RING,
+        "traffic": traffic,
+    }
+
+
+def timed_steps(model, step, steps, warmup, barrier):
+    """W untimed + K timed steps bracketed by barrier(); returns (seconds, event ms, counts, last result)."""
+    import ctypes
+
+    from aind_exaspim_neuron_segmentation_amd import _native
+
+    for _ in range(warmup):
+        out = step()
+        del out
+    lib = _native.lib()
+    mask = 0
+    for bit, _, _, _ in DOMINANT_CONVS:
+        mask |= 1 << bit
+    barrier()
+    _native.check(lib.exaspim_unet_timing_begin(model._engine, mask), "timing_begin")
+    out = None
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        del out             # the consumer is done with a result before it asks for the next one
+        out = step()        # (else every second step finds no cached 12.9 GB block: a hipMalloc)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ms = (ctypes.c_double * 17)()
+    cnt = (ctypes.c_int32 * 17)()
+    _native.check(lib.exaspim_unet_timing_read(model._engine, ctypes.byref(ms), ctypes.byref(cnt)),
+                  "timing_read")
+    return elapsed, ms, cnt, out
+
+
+def config_leg(name, dtype, edge, batch, device, steps=2, warmup=1):
+    """One of BASELINE.json's other single-GPU configurations: device-resident steps on one
+    stream, the dominant kernel's roofline fraction and the parity of this dtype."""
+    import numpy as np
+    import torch
+
+    from aind_exaspim_neuron_segmentation_amd import inference, sharding
+
+    model = make_model(dtype, device)
+    gshape = (edge,) * 3
+    plan = inference.SlidingWindow(gshape, (96, 96, 96), (32, 32, 32), TRIM)
+    shard = sharding.Shard(plan, (1, 1), 0)
+    volume = inference.DeviceVolume(synth_block((0, 0, 0), gshape, gshape, device), np.uint16, (0, 0, 0), gshape)
+
+    def step():
+        return sharding.predict_shard(volume, model, plan, shard, n_channels=3, batch_size=batch,
+                                      brightness_clip=1000, normalization_percentiles=(1, 99.9), n_streams=1)
+
+    elapsed, ms, cnt, out = timed_steps(model, step, steps, warmup, torch.cuda.synchronize)
+    checksum = float(out.sum().item())
+    del out, volume
+    torch.cuda.empty_cache()
+    value = float(edge) ** 3 * steps / elapsed
+    leg = {
+        "config": name,
+        "workload": f"{edge}x{edge}x{edge} uint16 volume, 96^3 patches, overlap 32, trim 8, batch {batch}, {dtype}",
+        "dtype": dtype,
+        "value": value,
+        "unit": "voxels/s",
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3,
+        "reference_equivalent_tflops": value * FLOP_PER_PATCH_96 / 64 ** 3 / 1e12,
+        "output_checksum": checksum,
+        "roofline": dominant_roofline(ms, cnt, dtype, batch, len(shard.starts)),
+        "parity": parity_block(model, dtype),
+    }
+    del model
+    torch.cuda.empty_cache()
+    return leg
 
 
 def main():
@@ -232,14 +409,12 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    import ctypes
+    import datetime
 
     import numpy as np
     import torch
 
-    from aind_exaspim_neuron_segmentation_amd import _native, inference, sharding
-    from aind_exaspim_neuron_segmentation_amd.machine_learning.unet3d import UNet3D
-    from aind_exaspim_neuron_segmentation_amd.utils import synthetic
+    from aind_exaspim_neuron_segmentation_amd import inference, sharding
 
     # one rank per GPU; EXASPIM_DIST_BACKEND=gloo lets several ranks rehearse the
     # sharded path on a single GPU (device index wraps, transfers staged via host)
@@ -250,37 +425,47 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
+        # a rank that dies leaves its peers in a collective: bounded by this timeout, and the
+        # launcher (launch_ranks) stops them as soon as it sees the dead rank
+        timeout = datetime.timedelta(minutes=5)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, timeout=timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=timeout)
         group = dist.group.WORLD
+    if os.environ.get("EXASPIM_BENCH_FAIL_RANK") == str(rank):     # test hook: one rank dies alone
+        raise SystemExit(f"bench.py: injected failure of rank {rank}")
 
-    # model: random-init weights of the reference architecture (no checkpoints offline)
-    sd = synthetic.synth_state_dict(3, 1, seed=1)
-    model = UNet3D(output_channels=3, compute_dtype=args.dtype)
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-    model.to(device).eval()
+    model = make_model(args.dtype, device)
 
     # synthetic global volume over a (z, y) rank grid
     grid = sharding.rank_grid(world)
     gshape = tuple(args.size * m for m in GLOBAL_SHAPES[world])
     plan = inference.SlidingWindow(gshape, (96, 96, 96), (32, 32, 32), TRIM)
     shard = sharding.Shard(plan, grid, rank)
-    vol_t = torch.empty(shard.input_dims, dtype=torch.int16, device=device)
-    blk = _native.Block.make(shard.input_dims, shard.input_origin, gshape)
-    _native.check(
-        _native.lib().exaspim_synth_volume_u16(vol_t.data_ptr(), blk, 0, None), "synth"
-    )
-    volume = inference.DeviceVolume(vol_t, np.uint16, shard.input_origin, gshape)
-    torch.cuda.synchronize()
+    halo_mode = args.input_halo or "exchange"
+    exchange_halo = world > 1 and halo_mode == "exchange"
     exchange = {"seconds": 0.0}
+    if exchange_halo:
+        # every rank holds its disjoint sub-volume only; the halo arrives inside the step
+        core_t = synth_block(shard.core_origin, shard.core_dims, gshape, device)
+        volume = None
+    else:
+        core_t = None
+        volume = inference.DeviceVolume(synth_block(shard.input_origin, shard.input_dims, gshape, device),
+                                        np.uint16, shard.input_origin, gshape)
+    torch.cuda.synchronize()
 
-    def step():
+    def step(n_streams=args.streams, timings=exchange):
+        vol = volume
+        if exchange_halo:
+            block = sharding._timed(timings, "input_halo_s", device,
+                                    lambda: sharding.exchange_input_halo(core_t, shard, group))
+            vol = inference.DeviceVolume(block, np.uint16, shard.input_origin, gshape)
         return sharding.predict_shard(
-            volume, model, plan, shard, n_channels=3, batch_size=args.batch,
+            vol, model, plan, shard, n_channels=3, batch_size=args.batch,
             brightness_clip=1000, normalization_percentiles=(1, 99.9), group=group,
-            n_streams=args.streams, timings=exchange,
+            n_streams=n_streams, timings=timings, core=core_t,
         )
 
     def barrier():
@@ -290,44 +475,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.cuda.device(device):
-        model._ensure_engine(device)  # pack + upload weights before anything is timed
+    def timed_step():
+        return step()
+
     for _ in range(args.warmup):
         out = step()
         del out
-    lib = _native.lib()
-    mask = 0
-    for bit, _, _, _ in DOMINANT_CONVS:
-        mask |= 1 << bit
-    barrier()
+    exchange.clear()
     exchange["seconds"] = 0.0
-    _native.check(lib.exaspim_unet_timing_begin(model._engine, mask), "timing_begin")
-    out = None
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        del out             # the consumer is done with a result before it asks for the next one
-        out = step()        # (else every second step finds no cached 12.9 GB block: a hipMalloc)
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    ms = (ctypes.c_double * 17)()
-    cnt = (ctypes.c_int32 * 17)()
-    _native.check(lib.exaspim_unet_timing_read(model._engine, ctypes.byref(ms), ctypes.byref(cnt)),
-                  "timing_read")
+    elapsed, ms, cnt, out = timed_steps(model, timed_step, args.steps, 0, barrier)
     checksum = float(out.sum().item())
     del out
-    # The same K steps with several batches in flight (predict(..., n_streams=k)): kernels of
-    # different batches then share the device, one kernel's ramp-down overlaps another batch's
-    # work, and a kernel's event-timed duration no longer measures that kernel -- which is why
-    # `value` and `roofline` above are single-stream. Reported next to them, never as `value`.
+    # The same K steps with several batches in flight (predict(..., n_streams=k), predict()'s
+    # default): kernels of different batches then share the device, one kernel's ramp-down overlaps
+    # another batch's work, and a kernel's event-timed duration no longer measures that kernel --
+    # which is why `value` and `roofline` above are single-stream. Reported next to them, never as
+    # `value`.
     pipelined = None
     if world == 1 and args.pipelined_streams > 1 and args.streams == 1:
         def step_pipelined():
-            return sharding.predict_shard(
-                volume, model, plan, shard, n_channels=3, batch_size=args.batch,
-                brightness_clip=1000, normalization_percentiles=(1, 99.9), group=group,
-                n_streams=args.pipelined_streams, timings={"seconds": 0.0},
-            )
+            return step(n_streams=args.pipelined_streams, timings={"seconds": 0.0})
         out = step_pipelined()      # the worker streams' workspaces are allocated here
         del out
         barrier()
@@ -346,63 +513,46 @@ def main():
             "unit": "voxels/s",
             "ms_per_step": tp / psteps * 1e3,
             "output_checksum": float(out.sum().item()),
-            "what": "same steps with predict(..., n_streams=k): bit-identical result (stitching stays in "
+            "what": "same steps with predict()'s default n_streams: bit-identical result (stitching stays in "
                     "batch order on the caller's stream); per-kernel durations are not meaningful here",
         }
         del out
-    exchange_ms = exchange["seconds"] / max(args.steps, 1) * 1e3
+    per_step = 1e3 / max(args.steps, 1)
+    phases = [exchange.get("seconds", 0.0) * per_step, exchange.get("histogram_s", 0.0) * per_step,
+              exchange.get("input_halo_s", 0.0) * per_step, exchange.get("output_bands_s", 0.0) * per_step]
     if group is not None:
         import torch.distributed as dist
 
-        t = torch.tensor([elapsed, exchange_ms], dtype=torch.float64,
+        t = torch.tensor([elapsed] + phases, dtype=torch.float64,
                          device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, exchange_ms = float(t[0].item()), float(t[1].item())
+        elapsed, phases = float(t[0].item()), [float(v) for v in t[1:].tolist()]
+    exchange_ms, histogram_ms, input_halo_ms, output_bands_ms = phases
 
     if rank == 0:
         total_vox = float(gshape[0]) * gshape[1] * gshape[2]
         value = total_vox * args.steps / elapsed
-        # roofline of the dominant kernel symbol (the 32-cout MFMA convolution: up3.3 and
-        # up4.0 are the same instantiation, so rocprofv3's per-kernel average covers
-        # exactly these launches)
-        launches = sum(cnt[b] for b, _, _, _ in DOMINANT_CONVS)
-        k_ms = sum(ms[b] for b, _, _, _ in DOMINANT_CONVS)
-        flops = 0.0
-        for b, cin, cout, edge in DOMINANT_CONVS:
-            # up4.0 (bit 15) only computes what up4.3 reads of the voxels predict() keeps:
-            # trim - 1 voxels less on every face (exaspim_unet_forward_trimmed) = 82^3; of
-            # that the timed z-column launch covers the whole 8 x 16 (y, x) tiles, 82 x 80 x 80
-            # (the two 2-voxel-thick remainders run as separate, untimed thin-tile launches)
-            need = edge - 2 * (TRIM - 1) if b == 15 else edge
-            vox = need * zcol_main(need, 8) * zcol_main(need, 16) if b == 15 else need ** 3
-            flops += cnt[b] * 2.0 * 27 * cin * cout * args.batch * vox
-        # the last batch of a step may be short; scale by the real patch count
         patches_per_step = len(shard.starts)
-        full_batches = -(-patches_per_step // args.batch)
-        flops *= patches_per_step / float(full_batches * args.batch)
-        achieved = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-        peak = PEAK_TFLOPS[args.dtype]
-        launches_per_step = len(DOMINANT_CONVS) * full_batches
-        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC
-        # passes (FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md says;
-        # profiles/summarize.py); null when no pass exists for this dtype.
-        traffic = None
-        for rnd in ("r02", "r01"):
-            tpath = os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm_{args.dtype}.json")
-            if os.path.exists(tpath):
-                with open(tpath) as f:
-                    kernels = json.load(f).get("kernels", {})
-                tag = {"bf16": "BF16Tag", "fp16": "F16Tag", "fp32": "F32Tag"}[args.dtype]
-                entry = kernels.get(f"conv3x3x3_zpipe<{tag}, 6, 8, 16, 2, 4, 0, false>")
-                if entry:
-                    traffic = entry["hbm_bytes_per_launch"]
-                    break
         # FLOPs of the work actually launched: the trimmed forward skips the margin of
         # up4.0 (82^3 of 96^3) and up4.3 (80^3 of 96^3)
         skipped = 2.0 * 27 * (64 * 32 * (96 ** 3 - 82 ** 3) + 32 * 32 * (96 ** 3 - 80 ** 3))
         storage = {"fp16": "fp16 (IEEE half) storage", "bf16": "bf16 storage", "fp32": "fp32"}[args.dtype]
         name = CONFIG_NAMES.get(world)
         shape_txt = "x".join(str(v) for v in gshape)
+        if world > 1:
+            sharding_txt = (
+                "global patch grid partitioned by sub-volume over a (z, y) rank grid; per step a 512 KiB "
+                "histogram all-reduce, the 16-voxel output bands to the +z / +y neighbours and "
+                + ("the input halo FETCHED from the +z / +y / +z+y neighbours inside the timed step "
+                   "(exchange_input_halo; every rank synthesises only its disjoint sub-volume)"
+                   if exchange_halo else
+                   "every rank's input block (sub-volume + halo) synthesised in place (--input-halo synth: "
+                   "exchange_input_halo is not in the timed path)")
+                + "; the halo is 32 voxels = the patch overlap, which is all a rank's last patches read beyond "
+                  "its own sub-volume (BASELINE configs[3] words it as halo=48 = overlap + 2 x trim: the 16 "
+                  "extra voxels would only feed outputs that the trim discards)")
+        else:
+            sharding_txt = "single device"
         result = {
             "metric": f"affinity voxels/sec on 96^3 patches over a {shape_txt} volume, {world} MI355X",
             "value": value,
@@ -423,30 +573,18 @@ def main():
                                if name else " (between BASELINE.json configs[3] and configs[4])"),
                 "patches_per_step": patches_per_step * world,
                 "rank_grid_zy": list(grid),
-                "sharding": ("global patch grid partitioned by sub-volume; per step a 512 KiB histogram "
-                             "all-reduce and the 16-voxel output bands to the +z / +y neighbours; every "
-                             "rank's input block (sub-volume + 32-voxel halo) is synthesised in place, "
-                             "so exchange_input_halo is not in the timed path") if world > 1 else "single device",
+                "sharding": sharding_txt,
+                "input_halo": ("exchange" if exchange_halo else "synth") if world > 1 else None,
                 "exchange_ms": exchange_ms,
+                "histogram_ms": histogram_ms,
+                "input_halo_ms": input_halo_ms,
+                "output_bands_ms": output_bands_ms,
                 "reference_equivalent_tflops": value * FLOP_PER_PATCH_96 / 64 ** 3 / 1e12,
                 "launched_tflops": value * (FLOP_PER_PATCH_96 - skipped) / 64 ** 3 / 1e12,
                 "output_checksum": checksum,
                 "streams": args.streams,
             },
-            "roofline": {
-                "bound": "mfma",
-                "kernel": "conv3x3x3_zpipe<tile 6x8x16, 32 couts, no head, no pool> (launches: up3.3, up4.0)",
-                "algorithmic_flop_per_launch": flops / launches if launches else None,
-                "achieved": achieved,
-                "peak": peak,
-                "unit": "TFLOP/s",
-                "frac": achieved / peak,
-                "avg_launch_ms": k_ms / launches if launches else None,
-                "timed_launches": launches,
-                "steps_covered": launches / float(launches_per_step) if launches_per_step else None,
-                "timer_ring": TIMER_RING,
-                "traffic": traffic,
-            },
+            "roofline": dominant_roofline(ms, cnt, args.dtype, args.batch, patches_per_step),
         }
         if pipelined is not None:
             result["pipelined"] = pipelined
@@ -454,11 +592,28 @@ def main():
             if not args.no_parity:
                 result["parity"] = parity_block(model, args.dtype)
             if not args.no_host_to_host:
-                del volume, vol_t
+                del volume
                 torch.cuda.empty_cache()
                 result["host_to_host"] = host_to_host(model, args, args.size)
+            if not args.no_configs:
+                # the other single-GPU configurations of BASELINE.json, so that one driver-run line
+                # covers them: configs[1] in the parity-graded precision, configs[2] as literally worded
+                volume = None
+                del model
+                torch.cuda.empty_cache()
+                edge1 = max(96, args.size // 2)
+                result["configs"] = {
+                    "configs[1]": config_leg(
+                        "512x512x512, batch 8, fp32, 1 GPU" + (f" (edge scaled to {edge1})" if edge1 != 512 else ""),
+                        "fp32", edge1, 8, device),
+                    "configs[2]_bf16": config_leg(
+                        "1024x1024x1024, bf16 activations / fp32 accumulate, batch 16, 1 GPU (the literal wording; "
+                        "the headline line runs the same workload with IEEE-half storage, the 16-bit mode inside 1e-3)"
+                        + (f" (edge scaled to {args.size})" if args.size != 1024 else ""),
+                        "bf16", args.size, 16, device),
+                }
             if not args.no_cpu_baseline:
-                result["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.size)
+                result["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.size, args.cpu_batch)
         print(json.dumps(result), flush=True)
     if group is not None:
         import torch.distributed as dist

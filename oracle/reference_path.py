@@ -114,7 +114,7 @@ def double_conv(x, sd, prefix):
             training=False,
             eps=BN_EPS,
         )
-        x = F.leaky_relu(x, LEAKY_SLOPE)
+        x = F.leaky_relu(x, LEAKY_SLOPE, inplace=True)   # in place like the reference (unet3d.py:145,148)
     return x
 
 

@@ -274,6 +274,28 @@ def test_validation_tiling_matches_reference_golden(golden):
                                       g[f"case{i}_centers_kept"])
 
 
+def test_is_contained_is_two_sided_like_the_reference():
+    """img_util.py:472-474 requires 0 <= v + buffer < s AND 0 <= v - buffer < s per axis; the two
+    one-sided halves agree with it only for buffer >= 0. Known answers worked out from those two lines."""
+    from aind_exaspim_neuron_segmentation_amd.utils import img_util
+
+    def rule(voxel, shape, buffer):
+        return (all(0 <= v + buffer < s for v, s in zip(voxel, shape))
+                and all(0 <= v - buffer < s for v, s in zip(voxel, shape)))
+
+    assert img_util.is_contained((0, 0, 0), (10, 10, 10), buffer=-1) is False      # v + buffer = -1
+    assert img_util.is_contained((9, 9, 9), (10, 10, 10), buffer=-1) is False      # v - buffer = 10
+    assert img_util.is_contained((5, 5, 5), (10, 10, 10), buffer=-1) is True
+    assert img_util.is_contained((5, 5, 5), (10, 10, 10), buffer=5) is False       # v + buffer = 10
+    assert img_util.is_contained((5, 5, 5), (11, 11, 11), buffer=5) is True
+    rng = np.random.default_rng(3)
+    for _ in range(2000):
+        shape = tuple(int(v) for v in rng.integers(1, 12, 3))
+        voxel = tuple(int(v) for v in rng.integers(-3, 14, 3))
+        buffer = int(rng.integers(-4, 5))
+        assert img_util.is_contained(voxel, shape, buffer) == rule(voxel, shape, buffer)
+
+
 def test_dtype_rules_and_fractional_clip_percentiles_on_the_host():
     """Host logic behind the voxel dtypes predict() takes: storage dtype per image dtype,
     numpy's np.minimum promotion, and np.percentile rebuilt from a 65536-bin histogram in

@@ -1,11 +1,11 @@
 # HBM read bytes per launch of the z-column kernels for two library builds (MI355X box):
-#   tools/pmc_fetch_ab.sh "old new"
+#   tools/pmc_fetch_ab.sh "base new"      ("base" = the in-tree library, others build/variants/lib_<name>.so)
+# The variant is selected with EXASPIM_LIB; the product library is never overwritten.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-L=aind_exaspim_neuron_segmentation_amd/csrc
-cp $L/libexaspim_affinity.so $L/build/variants/lib_base.so
+L=$GRAFT_REPO_ROOT/aind_exaspim_neuron_segmentation_amd/csrc
 for v in $1; do
-  cp $L/build/variants/lib_$v.so $L/libexaspim_affinity.so
+  if [ "$v" = base ]; then unset EXASPIM_LIB; else export EXASPIM_LIB=$L/build/variants/lib_$v.so; fi
   rm -rf gpurun_out/pmc_f
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_f -- python3 bench.py --size 256 --steps 1 --warmup 0 --no-cpu-baseline --no-host-to-host --no-parity --pipelined-streams 0 > /dev/null 2>&1
   echo "== $v"
@@ -21,4 +21,3 @@ for k, v in sorted(d.items()):
 PY
   rm -rf gpurun_out/pmc_f
 done
-cp $L/build/variants/lib_base.so $L/libexaspim_affinity.so
