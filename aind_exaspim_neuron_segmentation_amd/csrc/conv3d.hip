@@ -224,7 +224,10 @@ __device__ __forceinline__ uint2 pack4<F32Tag>(float, float, float, float) { ret
 // queue behind it. Measured inside 512^3 steps (us per launch, two alternating repeats, r03): levels
 // 0 / 1 / 2 / 3 of the z-column kernel: inc.3 803 / 786 / 783 / 785, up4.0 803 / 788 / 788 / 789,
 // up4.3 499 / 486 / 484 / 486, up3.3 171 / 166 / 166 / 166; level 2 in conv3x3x3_t14 as well: the
-// 17 convolutions sum to 4617 instead of 4644 us per batch.
+// 17 convolutions sum to 4617 instead of 4644 us per batch. 16-bit types only: with float32 operands
+// (four 16-pass MFMAs per chunk-tap) the same hint makes conv3x3x3_t14 8 - 30 % SLOWER (512^3, batch 8:
+// down2.0 458 -> 608 us, up2.0 1808 -> 2439, the 17 convolutions 19.7 -> 21.5 ms per batch) and leaves
+// the z-column kernel where it was.
 #ifndef EXASPIM_SETPRIO
 #define EXASPIM_SETPRIO 2   // conv3x3x3_zpipe (0 = off)
 #endif
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
         }
 
         const bool more = c + 1 < nchunks;
-        if (EXASPIM_SETPRIO_T14) __builtin_amdgcn_s_setprio(EXASPIM_SETPRIO_T14);
+        if (ES == 2 && EXASPIM_SETPRIO_T14) __builtin_amdgcn_s_setprio(EXASPIM_SETPRIO_T14);
 #pragma unroll
         for (int t = 0; t < 27; ++t) {
             if (t + PD < 27) {
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
             // this fence hipcc hoists and sinks them across taps and the loop runs ~20 % slower
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (EXASPIM_SETPRIO_T14) __builtin_amdgcn_s_setprio(0);
+        if (ES == 2 && EXASPIM_SETPRIO_T14) __builtin_amdgcn_s_setprio(0);
         if (more) prime_weights(c + 1);
         if (c - cbeg < 4) EXA_TRACE(3 + 3 * (c - cbeg));
         if (DMA) {
@@ -995,7 +998,7 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
             for (int s = 0; s < D; ++s)
                 xr[s % R] = lds[col + (s % HZ) * PLANE + ((s / HZ) / 3) * HXP + (s / HZ) % 3];
             __builtin_amdgcn_sched_barrier(0);
-            if (EXASPIM_SETPRIO) __builtin_amdgcn_s_setprio(EXASPIM_SETPRIO);
+            if (ES == 2 && EXASPIM_SETPRIO) __builtin_amdgcn_s_setprio(EXASPIM_SETPRIO);
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int g = s / HZ, zin = s % HZ;
@@ -1022,7 +1025,7 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (EXASPIM_SETPRIO) __builtin_amdgcn_s_setprio(0);
+            if (ES == 2 && EXASPIM_SETPRIO) __builtin_amdgcn_s_setprio(0);
             if (c < 4) EXA_TRACE(3 + 3 * c);
             __syncthreads();   // every wave is done reading this chunk's image
             if (c < 4) EXA_TRACE(4 + 3 * c);

@@ -384,17 +384,33 @@ __global__ __launch_bounds__(256) void pad_split_kernel(const float* __restrict_
     }
 }
 
+#ifndef EXASPIM_ABLATE_FIRST
+#define EXASPIM_ABLATE_FIRST 0   // tools/layer_bench only (results wrong on purpose): 1 = no stores, 2 = no LDS
+#endif                           // transposition, 4 = one MFMA instead of six, 8 = no tap loads
+// raw buffer access: 32-bit offsets against a descriptor, wave-uniform part in the scalar offset
+typedef unsigned int u32x4_b __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t layer_rsrc(const void* base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
 // (no minimum-occupancy hint: asking for 4 / 6 / 8 waves per SIMD measured 365 / 1362 / 1537 us
 // against 302 us -- the two tap register sets want their ~100 registers)
-// ROWS: the patch width is a multiple of 32, so a 32-voxel group is a piece of one row
-// and its position is decoded once per wave with scalar arithmetic.
+// ROWS: the patch width is a multiple of 32, so a 32-voxel group is a piece of one row: its
+// position is decoded once per wave with scalar arithmetic, every tap load is a buffer load with a
+// lane-constant offset (tap offset + lane's x) plus the group's scalar offset, and every store a
+// buffer store likewise -- no per-group vector address arithmetic at all (r03; before, 16 64-bit
+// address pairs were rebuilt per group: 148 registers, three waves per SIMD).
+// The next group's 16 tap loads are issued UNCONDITIONALLY (the group index is clamped, the last
+// prefetch of a wave is simply not used): behind a branch hipcc's wait-count insertion assumed the
+// not-taken path at the join and made every group wait for its successor's loads as well
+// (s_waitcnt vmcnt(0) in front of the matrix instructions) -- the double buffering never overlapped.
 template <typename T, bool ROWS>
 __global__ __launch_bounds__(256) void conv_first16_kernel(
     const unsigned* __restrict__ xp, const float* __restrict__ w,
     const float* __restrict__ bias, void* __restrict__ dst, int nvox, int d, int h, int wd,
     int c0p, float slope) {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, r = lane & 31;
     const int co_tile = blockIdx.y * 32;
     const int hw = h * wd, dhw = d * hw;
@@ -413,6 +429,7 @@ __global__ __launch_bounds__(256) void conv_first16_kernel(
             const int tt = real ? t : 0;
             wv[j] = real ? w[tt * c0p + co_tile + r] : 0.f;   // zero weight for the padding taps
             rel[st][j] = (tt / 9) * phw + ((tt / 3) % 3) * pw + tt % 3;
+            if (ROWS) rel[st][j] = (rel[st][j] + r) * 4;      // byte offset incl. the lane's x
         }
         split8<T>(wv, whi[st], wlo[st]);
     }
@@ -434,39 +451,53 @@ __global__ __launch_bounds__(256) void conv_first16_kernel(
     // matrix pipe, LDS and the stores (a group alone is a chain of latencies)
     const int ngroups = (nvox + 31) / 32;
     struct Pos {
-        const unsigned* base;   // padded address of tap (0,0,0) = voxel (zz-1, yy-1, xx-1)
-        int v, nb, sp;
+        const unsigned* base;   // !ROWS: padded address of tap (0,0,0) = voxel (zz-1, yy-1, xx-1)
+        int v, nb, sp;          // !ROWS: per lane; ROWS: nb and sp (first voxel of the group) are scalar
+        unsigned soff;          // ROWS: byte offset of the group's tap (0,0,0) inside its padded patch
     };
+    const size_t xpatch_bytes = (size_t)(d + 2) * phw * 4;               // one padded patch
+    const size_t opatch_bytes = (size_t)(c0p * ES / 32) * dhw * 32;      // one output patch, all chunk planes
     auto locate = [&](int grp) {
         Pos p;
-        int zz, yy, xx;
         if (ROWS) {
             const int g0 = __builtin_amdgcn_readfirstlane(grp) * 32;   // first voxel of the group
             p.nb = g0 / dhw;
-            const int sp0 = g0 - p.nb * dhw;
-            zz = sp0 / hw;
-            yy = (sp0 - zz * hw) / wd;
-            xx = sp0 - zz * hw - yy * wd + r;
-            p.sp = sp0 + r;
-            p.v = g0 + r;
+            p.sp = g0 - p.nb * dhw;
+            const int zz = p.sp / hw, yy = (p.sp - zz * hw) / wd, xx = p.sp - zz * hw - yy * wd;
+            p.soff = (unsigned)((zz * phw + yy * pw + xx) * 4);
+            p.v = g0;
+            p.base = nullptr;
         } else {
             p.v = grp * 32 + r;
             const int vc = p.v < nvox ? p.v : nvox - 1;
             p.nb = vc / dhw; p.sp = vc - p.nb * dhw;
-            zz = p.sp / hw; yy = (p.sp - zz * hw) / wd; xx = p.sp - zz * hw - yy * wd;
+            const int zz = p.sp / hw, yy = (p.sp - zz * hw) / wd, xx = p.sp - zz * hw - yy * wd;
+            p.base = xp + ((size_t)p.nb * (d + 2) + zz) * phw + yy * pw + xx;
+            p.soff = 0;
         }
-        p.base = xp + ((size_t)p.nb * (d + 2) + zz) * phw + yy * pw + xx;
         return p;
     };
     const int gstep = gridDim.x * 4;
     int grp = blockIdx.x * 4 + wave;
     if (grp >= ngroups) return;
     auto load_taps = [&](const Pos& p, unsigned (*x)[8]) {   // hi | lo << 16 per tap (pad_split_kernel)
+        if (ROWS) {
+            const __amdgpu_buffer_rsrc_t rs =
+                layer_rsrc(reinterpret_cast<const char*>(xp) + (size_t)p.nb * xpatch_bytes, xpatch_bytes);
 #pragma unroll
-        for (int st = 0; st < 2; ++st)
+            for (int st = 0; st < 2; ++st)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[st][j] = p.base[rel[st][j]];
+                for (int j = 0; j < 8; ++j)
+                    x[st][j] = (EXASPIM_ABLATE_FIRST & 8) ? (unsigned)(rel[st][j] + p.soff)
+                                                          : __builtin_amdgcn_raw_buffer_load_b32(rs, rel[st][j], (int)p.soff, 0);
+        } else {
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[st][j] = p.base[rel[st][j]];
+        }
     };
+    const int vv = lane >> 1, sub = lane & 1;
     auto process = [&](const Pos& cur, int g, const unsigned (*x)[8]) {
         f32x16_ct acc;
 #pragma unroll
@@ -483,11 +514,14 @@ __global__ __launch_bounds__(256) void conv_first16_kernel(
             xhi.z = __builtin_amdgcn_perm(x[st][5], x[st][4], 0x05040100u); xlo.z = __builtin_amdgcn_perm(x[st][5], x[st][4], 0x07060302u);
             xhi.w = __builtin_amdgcn_perm(x[st][7], x[st][6], 0x05040100u); xlo.w = __builtin_amdgcn_perm(x[st][7], x[st][6], 0x07060302u);
             mma_ct<T>(acc, whi[st], xhi);
+            if ((EXASPIM_ABLATE_FIRST & 4) && st == 0) { acc[1] += __uint_as_float(xlo.x ^ xhi.y); continue; }
+            if (EXASPIM_ABLATE_FIRST & 4) { acc[2] += __uint_as_float(xlo.z ^ xhi.w); continue; }
             mma_ct<T>(acc, whi[st], xlo);
             mma_ct<T>(acc, wlo[st], xhi);
         }
         // LeakyReLU, then through LDS so that each store instruction writes the 32 voxel
         // records of one chunk plane
+        uint2 direct[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int cl = 8 * q + 4 * half;
@@ -495,26 +529,47 @@ __global__ __launch_bounds__(256) void conv_first16_kernel(
             const f32x2_t a1 = leaky2((f32x2_t){acc[4 * q + 2], acc[4 * q + 3]}, slope);
             const float o8[8] = {a0.x, a0.y, a1.x, a1.y, 0.f, 0.f, 0.f, 0.f};
             const uint4 pk = T::pack(o8);
-            *reinterpret_cast<uint2*>(wl + r * RECP + cl * ES) = make_uint2(pk.x, pk.y);
+            direct[q] = make_uint2(pk.x, pk.y);
+            if (!(EXASPIM_ABLATE_FIRST & 2)) *reinterpret_cast<uint2*>(wl + r * RECP + cl * ES) = direct[q];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const int vv = lane >> 1, sub = lane & 1;
-        int vo, nbo, spo;
-        if (ROWS) {
-            vo = cur.v - r + vv; nbo = cur.nb; spo = cur.sp - r + vv;
-        } else {
-            vo = g * 32 + vv;
-            const int voc = vo < nvox ? vo : nvox - 1;
-            nbo = voc / dhw; spo = voc - nbo * dhw;
-        }
-        char* const dplane = static_cast<char*>(dst) +
-                             ((size_t)nbo * (c0p * ES / 32) + blockIdx.y * CPT) * dhw * 32;
+        if (ROWS && (EXASPIM_ABLATE_FIRST & 3)) {
+            const __amdgpu_buffer_rsrc_t rs =
+                layer_rsrc(static_cast<char*>(dst) + (size_t)cur.nb * opatch_bytes, opatch_bytes);
 #pragma unroll
-        for (int ck = 0; ck < CPT; ++ck) {
-            const uint4 val = *reinterpret_cast<const uint4*>(wl + vv * RECP + (ck * 2 + sub) * 16);
-            if (vo < nvox)
-                *reinterpret_cast<uint4*>(dplane + ((size_t)ck * dhw + spo) * 32 + sub * 16) = val;
+            for (int ck = 0; ck < CPT; ++ck) {
+                uint4 val = (EXASPIM_ABLATE_FIRST & 2)
+                                ? make_uint4(direct[2 * ck].x, direct[2 * ck].y, direct[2 * ck + 1].x, direct[2 * ck + 1].y)
+                                : *reinterpret_cast<const uint4*>(wl + vv * RECP + (ck * 2 + sub) * 16);
+                const u32x4_b d4 = {val.x, val.y, val.z, val.w};
+                if (!(EXASPIM_ABLATE_FIRST & 1) || val.x == 0x12345678u)
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        d4, rs, vv * 32 + sub * 16, (int)(((unsigned)(blockIdx.y * CPT + ck) * (unsigned)dhw + (unsigned)cur.sp) * 32u), 0);
+            }
+        } else if (ROWS) {
+            // one store instruction = the group's 32 voxel records of one chunk plane, 1 KiB contiguous
+            const __amdgpu_buffer_rsrc_t rs =
+                layer_rsrc(static_cast<char*>(dst) + (size_t)cur.nb * opatch_bytes, opatch_bytes);
+#pragma unroll
+            for (int ck = 0; ck < CPT; ++ck) {
+                const uint4 val = *reinterpret_cast<const uint4*>(wl + vv * RECP + (ck * 2 + sub) * 16);
+                const u32x4_b d4 = {val.x, val.y, val.z, val.w};
+                __builtin_amdgcn_raw_buffer_store_b128(
+                    d4, rs, vv * 32 + sub * 16, (int)(((unsigned)(blockIdx.y * CPT + ck) * (unsigned)dhw + (unsigned)cur.sp) * 32u), 0);
+            }
+        } else {
+            const int vo = g * 32 + vv;
+            const int voc = vo < nvox ? vo : nvox - 1;
+            const int nbo = voc / dhw, spo = voc - nbo * dhw;
+            char* const dplane = static_cast<char*>(dst) +
+                                 ((size_t)nbo * (c0p * ES / 32) + blockIdx.y * CPT) * dhw * 32;
+#pragma unroll
+            for (int ck = 0; ck < CPT; ++ck) {
+                const uint4 val = *reinterpret_cast<const uint4*>(wl + vv * RECP + (ck * 2 + sub) * 16);
+                if (vo < nvox)
+                    *reinterpret_cast<uint4*>(dplane + ((size_t)ck * dhw + spo) * 32 + sub * 16) = val;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -524,14 +579,17 @@ __global__ __launch_bounds__(256) void conv_first16_kernel(
     Pos pa = locate(grp), pb = pa;
     load_taps(pa, xa);
     for (;;) {
-        if (grp + gstep < ngroups) { pb = locate(grp + gstep); load_taps(pb, xb); }
+        const int g1 = grp + gstep;
+        pb = locate(g1 < ngroups ? g1 : ngroups - 1);
+        load_taps(pb, xb);
         process(pa, grp, xa);
-        grp += gstep;
-        if (grp >= ngroups) break;
-        if (grp + gstep < ngroups) { pa = locate(grp + gstep); load_taps(pa, xa); }
-        process(pb, grp, xb);
-        grp += gstep;
-        if (grp >= ngroups) break;
+        if (g1 >= ngroups) break;
+        const int g2 = g1 + gstep;
+        pa = locate(g2 < ngroups ? g2 : ngroups - 1);
+        load_taps(pa, xa);
+        process(pb, g1, xb);
+        if (g2 >= ngroups) break;
+        grp = g2;
     }
 }
 
@@ -807,18 +865,21 @@ int launch_conv_first(int dtype, const float* x, float* xpad, const float* w, co
     // the 16-bit kernel's waves walk the 32-voxel groups: 8 workgroups per CU are plenty
     const size_t groups = (nvox + 31) / 32;
     dim3 grid16((unsigned)(groups / 4 < 2048 ? (groups + 3) / 4 : 2048), c0p / 32);
+    // ROWS variant: whole 32-voxel groups inside a row, one padded / output patch per 32-bit descriptor
+    const bool rows = wd % 32 == 0 && (size_t)(d + 2) * (h + 2) * (wd + 2) * 4 < 0x7fffffffULL &&
+                      (size_t)c0p * 2 * d * h * wd < 0x7fffffffULL;
     switch (dtype) {
         case EXASPIM_DT_F32:
             conv_first_kernel<F32T, MT><<<grid, 256, 0, stream>>>(xpad, w, bias, dst, (int)nvox, d, h, wd, c0p, slope);
             break;
         case EXASPIM_DT_BF16:
-            if (wd % 32 == 0)
+            if (rows)
                 conv_first16_kernel<BF16T, true><<<grid16, 256, 0, stream>>>(xsplit, w, bias, dst, (int)nvox, d, h, wd, c0p, slope);
             else
                 conv_first16_kernel<BF16T, false><<<grid16, 256, 0, stream>>>(xsplit, w, bias, dst, (int)nvox, d, h, wd, c0p, slope);
             break;
         case EXASPIM_DT_F16:
-            if (wd % 32 == 0)
+            if (rows)
                 conv_first16_kernel<F16T, true><<<grid16, 256, 0, stream>>>(xsplit, w, bias, dst, (int)nvox, d, h, wd, c0p, slope);
             else
                 conv_first16_kernel<F16T, false><<<grid16, 256, 0, stream>>>(xsplit, w, bias, dst, (int)nvox, d, h, wd, c0p, slope);

@@ -125,10 +125,51 @@ def test_bench_launches_its_own_ranks():
     assert "256x128x128" in d["metric"] and "256x128x128" in d["config"]["workload"]
     assert d["config"]["rank_grid_zy"] == [2, 1] and d["config"]["exchange_ms"] >= 0
     assert d["roofline"]["timed_launches"] > 0 and "cpu_baseline" not in d
+    # north_star's exchange is inside the timed step: every rank holds its disjoint sub-volume and
+    # fetches the halo from its neighbours; the three exchange phases are reported separately
+    cfg = d["config"]
+    assert cfg["input_halo"] == "exchange" and "exchange_input_halo" in cfg["sharding"]
+    assert cfg["input_halo_ms"] > 0 and cfg["histogram_ms"] > 0 and cfg["output_bands_ms"] > 0
+    assert abs(cfg["exchange_ms"] - (cfg["input_halo_ms"] + cfg["histogram_ms"] + cfg["output_bands_ms"])) \
+        <= 0.5 * cfg["exchange_ms"] + 1.0      # (each figure is a max over ranks)
+    synth = subprocess.run(
+        [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--size", "128", "--steps", "1",
+         "--warmup", "0", "--no-cpu-baseline", "--input-halo", "synth"],
+        env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert synth.returncode == 0, synth.stderr[-2000:]
+    d2 = json.loads([ln for ln in synth.stdout.splitlines() if ln.startswith("{")][0])
+    assert d2["config"]["input_halo"] == "synth" and d2["config"]["input_halo_ms"] == 0
+    # the same volume either way: the result does not depend on where the halo came from
+    assert d2["config"]["output_checksum"] == d["config"]["output_checksum"]
     # a failing rank makes the launcher exit non-zero
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--size", "16"],   # no patch fits: Shard raises in every rank
                          env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert bad.returncode != 0
+
+
+def test_bench_stops_the_other_ranks_when_one_rank_dies():
+    """Only rank 1 fails (test hook EXASPIM_BENCH_FAIL_RANK): rank 0 would sit in its first collective
+    waiting for it. The launcher polls its children, stops the survivor and exits non-zero -- long
+    before the process group's own timeout."""
+    import subprocess
+    import sys
+    import time
+
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EXASPIM_DIST_BACKEND="gloo", EXASPIM_BENCH_FAIL_RANK="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.perf_counter()
+    out = subprocess.run(
+        [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--size", "128", "--steps", "1",
+         "--warmup", "0", "--no-cpu-baseline"],
+        env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    took = time.perf_counter() - t0
+    assert out.returncode != 0 and "ranks failed" in out.stderr and "(1," in out.stderr, out.stderr[-1500:]
+    assert took < 240, took
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
 
 
 def test_rccl_transport_rehearsal_on_one_rank():
@@ -252,3 +293,118 @@ def test_rank_block_of_the_8_gpu_workload_indexes_beyond_2_31():
     a = big[(slice(None),) + shard.local(lo, pure_hi, shard.accum_origin)]
     assert torch.equal(a, small[(slice(None),) + shard.local(lo, pure_hi, lo)])
     assert float(a.max()) <= 1.0 and float(a[:, 8:, 8:, 8:].min()) > 0.0
+
+
+def _stream_worker(rank, world, port, failures):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from aind_exaspim_neuron_segmentation_amd import inference, sharding
+
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        model = _model(dev)
+        gvol = synthetic.synth_volume(GSHAPE, seed=3)
+        plan = inference.SlidingWindow(GSHAPE, KW["patch_shape"], KW["overlap"], KW["trim"])
+        shard = sharding.Shard(plan, sharding.rank_grid(world), rank)
+        group = dist.group.WORLD
+        # the whole-accumulator route
+        core_sl = tuple(slice(o, o + d) for o, d in zip(shard.core_origin, shard.core_dims))
+        core = torch.from_numpy(np.ascontiguousarray(gvol[core_sl]).view(np.int16)).to(dev)
+        block = sharding.exchange_input_halo(core, shard, group)
+        volume = inference.DeviceVolume(block, np.uint16, shard.input_origin, GSHAPE)
+        accum = sharding.predict_shard(volume, model, plan, shard, n_channels=3, batch_size=5, group=group)
+        want = sharding.owned_result(accum, shard).cpu().numpy()
+        # reader -> rank block -> result, resident input
+        got = sharding.predict_shard_streaming(gvol, model, plan, shard, batch_size=5, group=group)
+        np.testing.assert_array_equal(got, want)
+        # read_box function, input read slab by slab, sink, thin slabs, half-precision export
+        inference.release_pinned_buffers()
+        old_cap = inference.PINNED_SLOT_BYTES
+        inference.PINNED_SLOT_BYTES = 5 * 3 * GSHAPE[1] * GSHAPE[2] * 4      # five planes of the global plane
+        try:
+            boxes = []
+
+            def read_box(lo, hi):
+                in_hi = tuple(o + d for o, d in zip(shard.input_origin, shard.input_dims))
+                assert all(a >= o and b <= h for a, b, o, h in zip(lo, hi, shard.input_origin, in_hi))
+                return gvol[tuple(slice(a, b) for a, b in zip(lo, hi))]
+
+            def sink(lo, hi, blk):
+                assert blk.dtype == np.float16 and hi[0] - lo[0] <= 5
+                boxes.append((lo, hi, blk.copy()))
+
+            out = sharding.predict_shard_streaming(read_box, model, plan, shard, batch_size=5, group=group,
+                                                   dtype=np.uint16, keep_input_resident=False,
+                                                   write_block=sink, out_dtype=np.float16)
+        finally:
+            inference.PINNED_SLOT_BYTES = old_cap
+        assert out is None
+        full = np.full(want.shape, np.nan, np.float16)
+        for lo, hi, blk in boxes:
+            full[(slice(None),) + tuple(slice(a - o, b - o) for a, b, o in zip(lo, hi, shard.own_lo))] = blk
+        np.testing.assert_array_equal(full.view(np.uint16), want.astype(np.float16).view(np.uint16))
+    except Exception as exc:
+        failures.put(f"rank {rank}: {type(exc).__name__}: {exc}")
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_streamed_shards_equal_predict_shard_bit_for_bit(world):
+    """sharding.predict_shard_streaming (reader -> rank blocks -> sink) with the real
+    kernels: each rank reads only its block of the global array, parks its first z-band planes until
+    the -z neighbour's band arrives, trades y rows slab by slab -- and its output region equals
+    predict_shard's (whole block resident, whole accumulator returned) bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    ctx = mp.get_context("spawn")
+    failures = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stream_worker, args=(r, world, port, failures)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+    msgs = []
+    while not failures.empty():
+        msgs.append(failures.get())
+    assert not msgs, msgs
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+
+def test_streamed_shard_footprint_does_not_grow_with_the_block_depth():
+    """One rank of a z-split grid, run on its own (group=None: its bands simply stay where they are):
+    with a read_box source, a sink and keep_input_resident=False the device holds one input slab,
+    two one-layer accumulators, the parked band planes and the output slots whatever the depth of
+    the rank's block. A 4x deeper block peaks at the same device memory."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from aind_exaspim_neuron_segmentation_amd import inference, sharding
+
+    dev = torch.device("cuda:0")
+    model = _model(dev)
+    kw = dict(patch_shape=(32, 32, 32), overlap=(8, 8, 8), trim=4)
+
+    def run(depth):
+        gshape = (2 * depth, 96, 96)
+        gvol = synthetic.synth_volume(gshape, seed=3)
+        plan = inference.SlidingWindow(gshape, kw["patch_shape"], kw["overlap"], kw["trim"])
+        shard = sharding.Shard(plan, (2, 1), 1)
+        csum = [0.0]
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats(dev)
+        base = torch.cuda.memory_allocated(dev)
+        sharding.predict_shard_streaming(lambda lo, hi: gvol[tuple(slice(a, b) for a, b in zip(lo, hi))],
+                                         model, plan, shard, batch_size=9, dtype=gvol.dtype,
+                                         keep_input_resident=False,
+                                         write_block=lambda lo, hi, b: csum.__setitem__(0, csum[0] + float(b.sum())))
+        assert csum[0] > 0
+        return torch.cuda.max_memory_allocated(dev) - base
+
+    run(104)        # warm-up: workspace and staging buffers exist afterwards
+    shallow, deep = run(264), run(1056)
+    print(f"peak device bytes above baseline: block depth 264 -> {shallow}, 1056 -> {deep}")
+    assert deep <= shallow + (1 << 20)

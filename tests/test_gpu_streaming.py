@@ -198,3 +198,68 @@ def test_half_precision_export(dev):
         src = torch.rand(n + 4, device=dev)[:n].contiguous()
         out = inference.export_half(src)
         assert torch.equal(out, src.to(torch.float16))
+
+
+def test_concurrent_predict_calls_do_not_share_staging_memory(dev):
+    """Two host threads call predict() at the same time (the pattern of one process driving
+    several GPUs; here both on the one device, with different volumes and different models):
+    every call checks its staging buffers out of the per-device pool, so neither overwrites
+    the other's slabs. Each result equals the one the same call gives on its own."""
+    import threading
+
+    from aind_exaspim_neuron_segmentation_amd import inference
+
+    kw = dict(patch_shape=(32, 32, 32), overlap=(8, 8, 8), trim=4, batch_size=5)
+    models = [make_model(dev, seed=1), make_model(dev, seed=2)]
+    vols = [synthetic.synth_volume((120, 72, 88), seed=30), synthetic.synth_volume((136, 88, 72), seed=31)]
+    alone = [inference.predict(v, m, verbose=False, **kw) for v, m in zip(vols, models)]
+    got, errors = [None, None], []
+    start = threading.Barrier(2)
+
+    def work(i):
+        try:
+            torch.cuda.set_device(dev)
+            start.wait(timeout=60)
+            for _ in range(3):
+                got[i] = inference.predict(vols[i], models[i], verbose=False, **kw)
+        except Exception as exc:          # surfaced below
+            errors.append(f"thread {i}: {type(exc).__name__}: {exc}")
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    for i in range(2):
+        np.testing.assert_array_equal(got[i], alone[i])
+    # the pool holds what the calls returned; releasing it empties it
+    assert any(inference._PINNED_FREE.values())
+    inference.release_pinned_buffers()
+    assert not any(inference._PINNED_FREE.values())
+
+
+def test_slabs_are_cut_to_the_staging_slot_size(dev, monkeypatch):
+    """A staging slot stays below inference.PINNED_SLOT_BYTES whatever the plane size: slabs are
+    cut thinner instead. With a tiny cap every emitted slab is one or two planes thick, the sink
+    still sees every plane exactly once, in z order, and the result does not change by a bit."""
+    from aind_exaspim_neuron_segmentation_amd import inference
+
+    model = make_model(dev)
+    kw = dict(patch_shape=(32, 32, 32), overlap=(8, 8, 8), trim=4, batch_size=5)
+    vol = synthetic.synth_volume((72, 56, 40), seed=8)
+    want = resident(vol, model, **kw)
+    monkeypatch.setattr(inference, "PINNED_SLOT_BYTES", 2 * 3 * 56 * 40 * 4)     # two planes
+    inference.release_pinned_buffers()
+    seen = []
+
+    def sink(z0, z1, b):
+        assert 0 < z1 - z0 <= 2 and b.shape == (3, z1 - z0, 56, 40)
+        seen.append((z0, z1, b.copy()))
+
+    inference.predict_streaming(vol, model, verbose=False, write_block=sink, **kw)
+    assert [s[0] for s in seen] == sorted(s[0] for s in seen)
+    assert seen[0][0] == 0 and seen[-1][1] == 72 and all(a[1] == b[0] for a, b in zip(seen, seen[1:]))
+    np.testing.assert_array_equal(np.concatenate([s[2] for s in seen], axis=1), want)
+    np.testing.assert_array_equal(inference.predict(vol, model, verbose=False, **kw), want)
+    inference.release_pinned_buffers()
