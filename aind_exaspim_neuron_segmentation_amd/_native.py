@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libexaspim_affinity.so")
 
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
-VOX_U8, VOX_U16, VOX_I16, VOX_F32 = 0, 1, 2, 3
+VOX_U8, VOX_U16, VOX_I16, VOX_F32, VOX_F64 = 0, 1, 2, 3, 4
 IN_F32, IN_PADDED_F32, IN_PADDED_SPLIT_F16, IN_PADDED_SPLIT_BF16 = 0, 1, 2, 3   # EXASPIM_IN_*
 UP_CONVT = 0x100   # EXASPIM_UP_CONVT: OR into a dtype code for UNet3D(trilinear=False)
 
@@ -86,10 +86,13 @@ SIGNATURES = {
     "exaspim_unet_input_layout": (_i32, [_vp]),
     "exaspim_unet_forward_prepared": (
         _i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "exaspim_unet_forward_absmax": (
+        _i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "exaspim_unet_timing_begin": (_i32, [_vp, ctypes.c_uint32]),
     "exaspim_unet_timing_read": (_i32, [_vp, ctypes.POINTER(ctypes.c_double * 17),
                                         ctypes.POINTER(ctypes.c_int32 * 17)]),
     "exaspim_histogram": (_i32, [_vp, _i32, _sz, ctypes.c_double, _i32, _i32, ctypes.c_uint32, _vp, _vp]),
+    "exaspim_histogram_wide": (_i32, [_vp, _i32, _sz, ctypes.c_double, _i32, _i32, ctypes.c_uint64, _vp, _vp]),
     "exaspim_gather_patches": (_i32, [_vp, _i32, ctypes.POINTER(Block), _vp, _i32, _I32x3,
                                       ctypes.c_double, _i32, ctypes.c_double, ctypes.c_double, _vp, _vp]),
     "exaspim_gather_patches_as": (_i32, [_vp, _i32, ctypes.POINTER(Block), _vp, _i32, _I32x3,

@@ -48,6 +48,40 @@ __device__ __forceinline__ uint4 record_half(uint2 lo_group, uint2 hi_group) {
 }
 
 
+// 16-byte MUBUF store with a scalar offset (range-checked against the descriptor: an offset at or
+// beyond its size is dropped by the hardware). gfx950 needs a wait state between such a store and a
+// vector-ALU write of its data registers -- tools/store_hazard.hip: without one 0.5 % of the stored
+// words are the NEW register contents (5 % with an immediate soffset, where one wait state is still
+// not enough and two are). hipcc's hazard recognizer guards only the form without a register soffset,
+// and with a single wait state, so the store carries its own s_nop 1. (Being inline assembly it is also
+// invisible to hipcc's s_waitcnt bookkeeping: nothing ever waits on these stores but the end of the
+// kernel -- which is what the epilogues want -- AND to its hazard recognizer: a descriptor or offset
+// SGPR written by the vector ALU right before (v_readlane of a spilled SGPR, v_readfirstlane) needs
+// five wait states before a memory instruction reads it, which hipcc inserts for its own instructions
+// only; without the leading s_nop 4 the store of the pooled epilogue went out with a half-restored
+// descriptor and faulted.)
+typedef unsigned int exa_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void buf_store16(const uint4& v, __amdgpu_buffer_rsrc_t rsrc, unsigned voff,
+                                            unsigned soff) {
+    const exa_u32x4 d = {v.x, v.y, v.z, v.w};
+    const unsigned ssoff = __builtin_amdgcn_readfirstlane(soff);   // (wave-uniform by contract)
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1"
+                 :: "v"(d), "v"(voff), "s"(rsrc), "s"(ssoff) : "memory");
+}
+
+// The same store through the compiler's builtin, for code whose later waits should COUNT it (a load
+// issued before it is then waited for with s_waitcnt vmcnt(#younger operations) instead of being made
+// to wait for the store as well). The scheduling fences keep any vector-ALU write of the data registers
+// from being placed between the store and its wait states.
+__device__ __forceinline__ void buf_store16_counted(const uint4& v, __amdgpu_buffer_rsrc_t rsrc, unsigned voff,
+                                                    unsigned soff) {
+    const exa_u32x4 d = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, (int)voff, (int)__builtin_amdgcn_readfirstlane(soff), 0);
+    asm volatile("s_nop 1");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // ---- network plan ---------------------------------------------------------
 // Channel counts are padded to multiples of 32 inside the workspace so that
 // every MFMA convolution sees whole 32-wide output tiles and whole 32-byte
@@ -196,6 +230,8 @@ int launch_maxpool2(int dtype, const void* src, void* dst, int n, int d, int h, 
 // d,h,w = INPUT size; output voxels within "margin" of a face are not computed
 int launch_upsample2(int dtype, const void* src, void* dst, int n, int d, int h, int w,
                      int c, int margin, hipStream_t stream);
+// *out = max(*out, largest |value| in the tensor) as float bits (out zeroed by the caller)
+int launch_absmax(int dtype, const void* src, size_t bytes, float* out, hipStream_t stream);
 int launch_head(int dtype, const void* src, const float* w, const float* bias,
                 float* out, int n, int d, int h, int wd, int c0p, int out_channels,
                 int apply_sigmoid, hipStream_t stream);

@@ -234,6 +234,12 @@ __device__ __forceinline__ uint2 pack4<F32Tag>(float, float, float, float) { ret
 #ifndef EXASPIM_SETPRIO_T14
 #define EXASPIM_SETPRIO_T14 2   // conv3x3x3_t14
 #endif
+#ifndef EXASPIM_BUFFER_STORES
+#define EXASPIM_BUFFER_STORES 7   // z-column kernel epilogues: branch-free range-checked buffer stores (1 direct, 2 head, 4 transposed + pool)
+#endif
+#ifndef EXASPIM_SETTLE_FIRST
+#define EXASPIM_SETTLE_FIRST 1    // z-column kernel: wait for the next tile's prefetch before the epilogue's stores
+#endif
 #ifndef EXASPIM_STAGE_FIRST
 #define EXASPIM_STAGE_FIRST 0   // 1: next tile's first chunk goes to LDS before the epilogue's stores (A/B aid)
 #endif
@@ -1035,6 +1041,19 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
                 if (c < 3) EXA_TRACE(5 + 3 * c);
             }
         }
+        // The next tile's prefetched pieces are waited for HERE, before the epilogue issues its stores
+        // (the empty asm makes every staged register "used", so hipcc puts the s_waitcnt for the
+        // prefetch loads in front of it; afterwards they are plain values). Left to the staging behind
+        // the epilogue, that wait is s_waitcnt vmcnt(0) and also covers the epilogue's stores -- a tile
+        // boundary then costs a full store round trip. A counted wait (vmcnt(#stores)) behind
+        // unconditional range-checked stores is NOT an alternative: a store the range check drops
+        // retires early, out of order with the older loads, and the count lets stale staging registers
+        // through (measured: trimmed forward no longer repeatable).
+        if (EXASPIM_SETTLE_FIRST && has_next) {
+#pragma unroll
+            for (int i = 0; i < NITEMS + WITEMS; ++i)
+                asm volatile("" : "+v"(stg[i].x), "+v"(stg[i].y), "+v"(stg[i].z), "+v"(stg[i].w));
+        }
         // epilogues that do not go through LDS leave the image free from here on
         constexpr bool kLdsFreeEpilogue = HEAD > 0 || (ES == 2 && !POOL && EXASPIM_DIRECT_EPILOGUE);
         if (EXASPIM_STAGE_FIRST && kLdsFreeEpilogue && has_next) stage_store();
@@ -1076,17 +1095,35 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
             }
             const size_t plane = (size_t)a.h * a.w;
             const int gy = cur.y0 + pos_e / TX, gx = cur.x0 + pos_e % TX;
+#if EXASPIM_BUFFER_STORES & 2
+            // (unconditional range-checked stores, see the direct epilogue below; outputs are dealt
+            // to the two half-waves: even ones are stored by lanes 0-31, odd ones by lanes 32-63)
+            const bool okyx = gy < a.org[1] + a.ext[1] && gx < a.org[2] + a.ext[2];
+            float* const hpatch = a.head_out + (size_t)cur.nb * HEAD * a.d * plane;
+            const size_t hbytes = (size_t)HEAD * a.d * plane * sizeof(float);
+            const unsigned hvoff[2] = {okyx && half_e == 0 ? (unsigned)(gy * a.w + gx) * 4u : kOutOfRange,
+                                       okyx && half_e == 1 ? (unsigned)(gy * a.w + gx) * 4u : kOutOfRange};
+#endif
 #pragma unroll
             for (int z = 0; z < TZ; ++z) {
                 const int gz = cur.z0 + z;
+#if EXASPIM_BUFFER_STORES & 2
+                const __amdgpu_buffer_rsrc_t hrsrc = make_rsrc(hpatch, gz < a.org[0] + a.ext[0] ? hbytes : (size_t)0);
+#else
                 const bool ok = gz < a.org[0] + a.ext[0] && gy < a.org[1] + a.ext[1] && gx < a.org[2] + a.ext[2];
+#endif
 #pragma unroll
                 for (int o = 0; o < HEAD; ++o) {
                     float t = part[z][o] + __shfl_xor(part[z][o], 32) + head_s[HEAD * 32 + o];
                     if (a.head_sigmoid) t = 1.f / (1.f + expf(-t));
+#if EXASPIM_BUFFER_STORES & 2
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t), hrsrc, (int)hvoff[o & 1],
+                                                          (int)((unsigned)(o * a.d + gz) * (unsigned)plane * 4u), 0);
+#else
                     // outputs are dealt to the two half-waves so both store
                     if (ok && (o & 1) == half_e)
                         a.head_out[(((size_t)cur.nb * HEAD + o) * a.d + gz) * plane + (size_t)gy * a.w + gx] = t;
+#endif
                 }
             }
         } else if (ES == 2 && !POOL && EXASPIM_DIRECT_EPILOGUE) {
@@ -1097,7 +1134,15 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
                                  ((size_t)cur.nb * (a.cout / KC) + ntile0 * 2) * patch_vox * 32;
             const int gy = cur.y0 + pos_e / TX, gx = cur.x0 + pos_e % TX;
             const bool okyx = gy < a.org[1] + a.ext[1] && gx < a.org[2] + a.ext[2];
+#if EXASPIM_BUFFER_STORES & 1
+            // Every store is ISSUED, as a range-checked buffer store: a lane outside the region gets
+            // an out-of-range offset and a plane outside it the zero-record descriptor, and the
+            // hardware drops the write -- no branch, no per-store address arithmetic on the vector ALU.
+            // (Nothing may COUNT on these stores, see EXASPIM_SETTLE_FIRST above.)
+            const unsigned ovoff = okyx ? (unsigned)(gy * a.w + gx) * 32u + half_e * 16u : kOutOfRange;
+#else
             char* const dvox = dplane + ((size_t)gy * a.w + gx) * 32 + half_e * 16;
+#endif
 #pragma unroll
             for (int z = 0; z < TZ; ++z) {
                 uint2 grp[4];
@@ -1109,8 +1154,16 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
 #pragma unroll
                 for (int ck = 0; ck < 2; ++ck) {
                     const uint4 rec = record_half(grp[2 * ck], grp[2 * ck + 1]);
+#if EXASPIM_BUFFER_STORES & 1
+                    const unsigned soff = ((unsigned)ck * (unsigned)patch_vox + (unsigned)gz * (unsigned)plane_vox) * 32u;
+                    // (descriptor with zero records for a plane outside the region: a scalar select, no branch)
+                    const __amdgpu_buffer_rsrc_t orsrc =
+                        make_rsrc(dplane, gz < a.org[0] + a.ext[0] ? (size_t)2 * patch_vox * 32 : (size_t)0);
+                    buf_store16(rec, orsrc, ovoff, soff);
+#else
                     if (okyx && gz < a.org[0] + a.ext[0] && (!(EXASPIM_ABLATE & 2) || rec.x == 0x12345u))
                         *reinterpret_cast<uint4*>(dvox + ((size_t)ck * patch_vox + (size_t)gz * plane_vox) * 32) = rec;
+#endif
                 }
             }
         } else {
@@ -1153,14 +1206,27 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
 #pragma unroll
                 for (int z = zb; z < zb + TB && z < TZ; ++z) {
                     const int gz = cur.z0 + z;
+#if EXASPIM_BUFFER_STORES & 4
+                    // (unconditional range-checked stores, see the direct epilogue above)
+                    const bool tokyx = ogy < a.org[1] + a.ext[1] && ogx < a.org[2] + a.ext[2];
+                    const unsigned tvoff = tokyx ? (unsigned)(ogy * a.w + ogx) * 32u + sub * 16u : kOutOfRange;
+                    const __amdgpu_buffer_rsrc_t trsrc =
+                        make_rsrc(dplane, gz < a.org[0] + a.ext[0] ? (size_t)CPT * patch_vox * 32 : (size_t)0);
+#else
                     const bool ok = gz < a.org[0] + a.ext[0] && ogy < a.org[1] + a.ext[1] && ogx < a.org[2] + a.ext[2];
                     const size_t vox = ((size_t)gz * a.h + ogy) * a.w + ogx;
+#endif
 #pragma unroll
                     for (int ck = 0; ck < CPT; ++ck) {
                         const uint4 val = *reinterpret_cast<const uint4*>(
                             wl + (z - zb) * (32 * RECP) + vv * RECP + (ck * 2 + sub) * 16);
+#if EXASPIM_BUFFER_STORES & 4
+                        buf_store16(val, trsrc, tvoff,
+                                    ((unsigned)ck * (unsigned)patch_vox + (unsigned)gz * (unsigned)plane_vox) * 32u);
+#else
                         if (ok && (!(EXASPIM_ABLATE & 2) || val.x == 0x12345u))
                             *reinterpret_cast<uint4*>(dplane + ((size_t)ck * patch_vox + vox) * 32 + sub * 16) = val;
+#endif
                     }
                 }
                 if (POOL) {
@@ -1172,13 +1238,29 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
                     const size_t pvox = (size_t)pd * ph * pw2;
                     char* const pplane = static_cast<char*>(a.pool_dst) +
                                          ((size_t)cur.nb * (a.cout / KC) + ntile0 * CPT) * pvox * 32;
+#if EXASPIM_BUFFER_STORES & 4
+                    const __amdgpu_buffer_rsrc_t prsrc = make_rsrc(pplane, (size_t)CPT * pvox * 32);
+#endif
 #pragma unroll
                     for (int p0 = 0; p0 < NP; p0 += 64) {
                         const int p = p0 + lane_e;
+#if EXASPIM_BUFFER_STORES & 4
+                        // a lane without a piece works on piece 0 and its store is dropped by the range
+                        // check: no branch around the LDS reads or the store (see the direct epilogue)
+                        const bool live0 = p < NP;
+                        const int pc = live0 ? p : 0;
+                        const int zp = pc / (8 * CPT * 2), rem = pc % (8 * CPT * 2);
+                        const int ck = rem / 16, xp = (rem % 16) >> 1, sb = rem & 1;
+                        const bool live = live0 && zb + 2 * zp + 1 < TZ;
+                        const int zr = zb + 2 * zp + 1 < TZ ? zp : 0;     // (rows that exist in the batch)
+                        {
+                            const char* rec = wl + (2 * zr) * (32 * RECP) + (2 * xp) * RECP + (ck * 2 + sb) * 16;
+#else
                         const int zp = p / (8 * CPT * 2), rem = p % (8 * CPT * 2);
                         const int ck = rem / 16, xp = (rem % 16) >> 1, sb = rem & 1;
                         if (p < NP && zb + 2 * zp + 1 < TZ) {
                             const char* rec = wl + (2 * zp) * (32 * RECP) + (2 * xp) * RECP + (ck * 2 + sb) * 16;
+#endif
                             uint4 m = *reinterpret_cast<const uint4*>(rec);
                             if (ES == 2) m = key16(m);   // 16-bit types: compare order-preserving keys
 #pragma unroll
@@ -1189,9 +1271,17 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
                             }
                             if (ES == 2) m = key16(m);
                             const int qz = (cur.z0 + zb) / 2 + zp, qy = cur.y0 / 2 + wave, qx = cur.x0 / 2 + xp;
+#if EXASPIM_BUFFER_STORES & 4
+                            const unsigned pvoff =
+                                live && qz < pd && qy < ph && qx < pw2
+                                    ? (unsigned)((ck * (int)pvox + (qz * ph + qy) * pw2 + qx) * 32 + sb * 16)
+                                    : kOutOfRange;
+                            buf_store16(m, prsrc, pvoff, 0u);
+#else
                             if (qz < pd && qy < ph && qx < pw2)
                                 *reinterpret_cast<uint4*>(pplane + ((size_t)ck * pvox +
                                                                     ((size_t)qz * ph + qy) * pw2 + qx) * 32 + sb * 16) = m;
+#endif
                         }
                     }
                 }

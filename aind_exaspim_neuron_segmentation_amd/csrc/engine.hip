@@ -82,9 +82,11 @@ static Workspace make_workspace(const UNetPlan& p, int n, int d, int h, int w) {
 }
 
 // x: float32 patches, or (x == nullptr) x_prepared: the first convolution's operand layout
+// absmax (optional): float[1 + kNumMfmaConvs + 4], the largest |activation| inc.0, every MFMA
+// convolution and every ConvTranspose3d stored (range probe: nothing is fused away, nothing trimmed)
 static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, int h, int w,
                    int apply_sigmoid, int trim, void* workspace, size_t workspace_bytes,
-                   hipStream_t stream, const void* x_prepared = nullptr) {
+                   hipStream_t stream, const void* x_prepared = nullptr, float* absmax = nullptr) {
     const UNetPlan& p = e->plan;
     const Workspace ws = make_workspace(p, n, d, h, w);
     if (workspace_bytes < ws.bytes) {
@@ -99,7 +101,7 @@ static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, in
     int rc;
 
     // the last conv (up4.3) can run the 1x1x1 head on its accumulators
-    const bool fuse_head = conv_can_fuse_head(p.conv[kNumMfmaConvs - 1].cout, w, p.out_channels);
+    const bool fuse_head = !absmax && conv_can_fuse_head(p.conv[kNumMfmaConvs - 1].cout, w, p.out_channels);
     // With the head fused, voxels within "trim" of a patch face are never read again:
     // up4.3 skips them, and up4.0 everything its 3x3x3 consumer does not reach.
     const bool trimmed = fuse_head && trim > 0 && 2 * trim < d && 2 * trim < h && 2 * trim < w;
@@ -179,6 +181,9 @@ static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, in
             b.org[2] = a.org[2] + a.ext[2]; b.ext[2] = rem_x;
             r = launch_conv3x3x3_thin(dt, b, stream);
         }
+        if (r == EXASPIM_OK && absmax)
+            r = launch_absmax(dt, dst, (size_t)n * (d >> l) * (h >> l) * (w >> l) * L.cout * dtype_size(dt),
+                              absmax + 1 + idx, stream);
         return r;
     };
 #define RUN(expr) do { rc = (expr); if (rc) return rc; } while (0)
@@ -189,6 +194,7 @@ static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, in
                           reinterpret_cast<const float*>(e->packed + p.first_w_off),
                           reinterpret_cast<const float*>(e->packed + p.first_b_off), A(0), n, d,
                           h, w, p.c0p, kLeakySlope, stream));
+    if (absmax) RUN(launch_absmax(dt, A(0), (size_t)n * d * h * w * p.c0p * dtype_size(dt), absmax, stream));
     RUN(conv(0, A(0), nullptr, skip(0), 0));                      // x1
     for (int l = 1; l <= 4; ++l) {
         const ConvLayer& L0 = p.conv[2 * l - 1];
@@ -209,6 +215,9 @@ static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, in
             RUN(launch_convt2(dt, prev, e->packed + U.w_off,
                               reinterpret_cast<const float*>(e->packed + U.b_off), A(l), n,
                               d >> (l + 1), h >> (l + 1), w >> (l + 1), U.cin, U.cout, stream));
+            if (absmax)     // (a transposed convolution is not bounded by its input like the interpolation is)
+                RUN(launch_absmax(dt, A(l), (size_t)n * (d >> l) * (h >> l) * (w >> l) * U.cout * dtype_size(dt),
+                                  absmax + 1 + kNumMfmaConvs + (3 - l), stream));
         } else {
             // up4.0 reads the upsampled tensor one voxel beyond its own trimmed output
             RUN(launch_upsample2(dt, prev, A(l), n, d >> (l + 1), h >> (l + 1), w >> (l + 1), L0.cb,
@@ -401,4 +410,17 @@ extern "C" int exaspim_unet_forward_trimmed(exaspim_unet* h, const float* x_dev,
                   d, hgt, w);
     return forward(h, x_dev, out_dev, n, d, hgt, w, apply_sigmoid, trim, workspace_dev,
                    workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int exaspim_unet_forward_absmax(exaspim_unet* h, const float* x_dev, float* out_dev,
+                                           int32_t n, int32_t d, int32_t hgt, int32_t w,
+                                           int32_t apply_sigmoid, float* absmax_dev,
+                                           void* workspace_dev, size_t workspace_bytes, void* stream) {
+    EXA_CHECK_ARG(h && x_dev && out_dev && workspace_dev && absmax_dev, "forward_absmax: NULL pointer");
+    EXA_CHECK_ARG(n > 0, "forward: empty batch");
+    EXA_CHECK_ARG(level_dims_ok(d, hgt, w),
+                  "forward: patch %dx%dx%d: every dimension must be a positive multiple of 16",
+                  d, hgt, w);
+    return forward(h, x_dev, out_dev, n, d, hgt, w, apply_sigmoid, 0, workspace_dev, workspace_bytes,
+                   (hipStream_t)stream, nullptr, absmax_dev);
 }

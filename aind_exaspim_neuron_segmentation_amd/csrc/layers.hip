@@ -384,6 +384,9 @@ __global__ __launch_bounds__(256) void pad_split_kernel(const float* __restrict_
     }
 }
 
+#ifndef EXASPIM_FIRST_HIDDEN_STORES
+#define EXASPIM_FIRST_HIDDEN_STORES 0   // inc.0: 1 = stores the compiler's wait counts do not see (measurement aid)
+#endif
 #ifndef EXASPIM_ABLATE_FIRST
 #define EXASPIM_ABLATE_FIRST 0   // tools/layer_bench only (results wrong on purpose): 1 = no stores, 2 = no LDS
 #endif                           // transposition, 4 = one MFMA instead of six, 8 = no tap loads
@@ -542,10 +545,8 @@ __global__ __launch_bounds__(256) void conv_first16_kernel(
                 uint4 val = (EXASPIM_ABLATE_FIRST & 2)
                                 ? make_uint4(direct[2 * ck].x, direct[2 * ck].y, direct[2 * ck + 1].x, direct[2 * ck + 1].y)
                                 : *reinterpret_cast<const uint4*>(wl + vv * RECP + (ck * 2 + sub) * 16);
-                const u32x4_b d4 = {val.x, val.y, val.z, val.w};
                 if (!(EXASPIM_ABLATE_FIRST & 1) || val.x == 0x12345678u)
-                    __builtin_amdgcn_raw_buffer_store_b128(
-                        d4, rs, vv * 32 + sub * 16, (int)(((unsigned)(blockIdx.y * CPT + ck) * (unsigned)dhw + (unsigned)cur.sp) * 32u), 0);
+                    buf_store16(val, rs, vv * 32 + sub * 16, ((unsigned)(blockIdx.y * CPT + ck) * (unsigned)dhw + (unsigned)cur.sp) * 32u);
             }
         } else if (ROWS) {
             // one store instruction = the group's 32 voxel records of one chunk plane, 1 KiB contiguous
@@ -554,9 +555,12 @@ __global__ __launch_bounds__(256) void conv_first16_kernel(
 #pragma unroll
             for (int ck = 0; ck < CPT; ++ck) {
                 const uint4 val = *reinterpret_cast<const uint4*>(wl + vv * RECP + (ck * 2 + sub) * 16);
-                const u32x4_b d4 = {val.x, val.y, val.z, val.w};
-                __builtin_amdgcn_raw_buffer_store_b128(
-                    d4, rs, vv * 32 + sub * 16, (int)(((unsigned)(blockIdx.y * CPT + ck) * (unsigned)dhw + (unsigned)cur.sp) * 32u), 0);
+#if EXASPIM_FIRST_HIDDEN_STORES
+                buf_store16(val, rs, vv * 32 + sub * 16, ((unsigned)(blockIdx.y * CPT + ck) * (unsigned)dhw + (unsigned)cur.sp) * 32u);
+#else
+                // counted: the wait for the next group's taps (issued before these stores) leaves them in flight
+                buf_store16_counted(val, rs, vv * 32 + sub * 16, ((unsigned)(blockIdx.y * CPT + ck) * (unsigned)dhw + (unsigned)cur.sp) * 32u);
+#endif
             }
         } else {
             const int vo = g * 32 + vv;
@@ -829,6 +833,32 @@ __global__ __launch_bounds__(256) void head_kernel(const uint4* __restrict__ src
     }
 }
 
+// ---- range probe: largest |value| of an activation tensor ----------------------
+// (exaspim_unet_forward_absmax: what a checkpoint's activations reach, per layer, before a
+// 16-bit storage type is trusted with them). Non-negative floats order like their bit
+// patterns, so the maximum is an atomicMax on unsigned.
+template <typename T>
+__global__ __launch_bounds__(256) void absmax_kernel(const uint4* __restrict__ src, size_t pieces,
+                                                     unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pieces;
+         i += (size_t)gridDim.x * blockDim.x) {
+        float f[T::kG];
+        T::unpack(src[i], f);
+#pragma unroll
+        for (int j = 0; j < T::kG; ++j) {
+            const float a = fabsf(f[j]);
+            m = a > m || a != a ? a : m;      // (a NaN is kept and reported)
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(m, off);
+        m = o > m || o != o ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
 // ---- launchers ----------------------------------------------------------------
 static inline unsigned stream_grid(size_t items) {
     const size_t blocks = (items + 255) / 256;
@@ -934,6 +964,16 @@ int launch_upsample2(int dtype, const void* src, void* dst, int n, int d, int h,
     DISPATCH_T(dtype, (upsample2_kernel<T><<<grid, 256, 0, stream>>>(
                           static_cast<const uint4*>(src), static_cast<uint4*>(dst), d, h, w,
                           scale(d), scale(h), scale(w), margin)));
+    EXA_CHECK_HIP(hipGetLastError());
+    return EXASPIM_OK;
+}
+
+int launch_absmax(int dtype, const void* src, size_t bytes, float* out, hipStream_t stream) {
+    EXA_CHECK_ARG(bytes % 16 == 0, "absmax: %zu bytes is not a whole number of 16-byte pieces", bytes);
+    if (bytes == 0) return EXASPIM_OK;
+    const size_t pieces = bytes / 16;
+    DISPATCH_T(dtype, (absmax_kernel<T><<<stream_grid(pieces), 256, 0, stream>>>(
+                          static_cast<const uint4*>(src), pieces, reinterpret_cast<unsigned*>(out))));
     EXA_CHECK_HIP(hipGetLastError());
     return EXASPIM_OK;
 }

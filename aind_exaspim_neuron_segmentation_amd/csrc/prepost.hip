@@ -82,6 +82,22 @@ __device__ __forceinline__ int bin_of<EXASPIM_VOX_F32>(const void* vol, size_t i
     return (k >> 16) == prefix ? (int)(k & 0xffffu) : -1;
 }
 
+// float64 voxels (images float32 cannot carry exactly: float64, or 32/64-bit integers converted on
+// the host): order-preserving 64-bit key, binned 16 bits per pass -- pass p bins key bits
+// [48 - 16p, 64 - 16p) of the voxels whose bits above that field equal "prefix".
+__device__ __forceinline__ unsigned long long f64_key(double f) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(f);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
+}
+__device__ __forceinline__ int bin_of_f64(const void* vol, size_t i, double clip, int has_clip, int pass,
+                                          unsigned long long prefix) {
+    double v = static_cast<const double*>(vol)[i];
+    if (has_clip && v > clip) v = clip;      // np.minimum: exact, the clip is a float64 itself
+    const unsigned long long k = f64_key(v);
+    if (pass > 0 && (k >> (64 - 16 * pass)) != prefix) return -1;
+    return (int)((k >> (48 - 16 * pass)) & 0xffffULL);
+}
+
 constexpr int kLdsBins = 16384;  // privatised window of the 65536 bins
 
 template <int VOX>
@@ -95,6 +111,28 @@ __global__ __launch_bounds__(256) void histogram_kernel(const void* __restrict__
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (size_t)gridDim.x * blockDim.x) {
         const int b = bin_of<VOX>(vol, i, clip, has_clip, pass, prefix);
+        if (b < 0) continue;
+        const int lb = b - window_lo;
+        if ((unsigned)lb < (unsigned)kLdsBins)
+            atomicAdd(&local[lb], 1u);
+        else
+            atomicAdd(&hist[b], 1ULL);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kLdsBins; i += blockDim.x) {
+        const unsigned c = local[i];
+        if (c) atomicAdd(&hist[window_lo + i], (unsigned long long)c);
+    }
+}
+
+__global__ __launch_bounds__(256) void histogram_f64_kernel(const void* __restrict__ vol, size_t n, double clip,
+                                                            int has_clip, int pass, unsigned long long prefix,
+                                                            int window_lo, unsigned long long* __restrict__ hist) {
+    __shared__ unsigned local[kLdsBins];
+    for (int i = threadIdx.x; i < kLdsBins; i += blockDim.x) local[i] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = bin_of_f64(vol, i, clip, has_clip, pass, prefix);
         if (b < 0) continue;
         const int lb = b - window_lo;
         if ((unsigned)lb < (unsigned)kLdsBins)
@@ -124,6 +162,7 @@ template <> __device__ __forceinline__ double load_voxel<EXASPIM_VOX_U8>(const v
 template <> __device__ __forceinline__ double load_voxel<EXASPIM_VOX_U16>(const void* v, size_t i) { return (double)static_cast<const uint16_t*>(v)[i]; }
 template <> __device__ __forceinline__ double load_voxel<EXASPIM_VOX_I16>(const void* v, size_t i) { return (double)static_cast<const int16_t*>(v)[i]; }
 template <> __device__ __forceinline__ double load_voxel<EXASPIM_VOX_F32>(const void* v, size_t i) { return (double)static_cast<const float*>(v)[i]; }
+template <> __device__ __forceinline__ double load_voxel<EXASPIM_VOX_F64>(const void* v, size_t i) { return static_cast<const double*>(v)[i]; }
 
 // How a gathered value leaves the kernel (LAYOUT = EXASPIM_IN_*): the float32 patch the ABI's
 // forward takes, or the first convolution's own operand layout -- a (pz + 2, py + 2, px + 2)
@@ -467,6 +506,24 @@ extern "C" int exaspim_histogram(const void* vol_dev, int32_t vox_dtype, size_t 
     return EXASPIM_OK;
 }
 
+extern "C" int exaspim_histogram_wide(const void* vol_dev, int32_t vox_dtype, size_t n, double clip,
+                                      int32_t has_clip, int32_t pass, uint64_t prefix,
+                                      uint64_t* hist_dev, void* stream) {
+    EXA_CHECK_ARG(vol_dev && hist_dev, "histogram: NULL pointer");
+    EXA_CHECK_ARG(vox_dtype == EXASPIM_VOX_F64, "histogram_wide: voxel dtype %d (only EXASPIM_VOX_F64)", vox_dtype);
+    EXA_CHECK_ARG(pass >= 0 && pass <= 3, "histogram_wide: pass %d outside 0..3", pass);
+    EXA_CHECK_ARG(pass == 0 ? prefix == 0 : (prefix >> (16 * pass)) == 0, "histogram_wide: prefix wider than %d bits", 16 * pass);
+    if (n == 0) return EXASPIM_OK;
+    const size_t blocks = (n + 256 * 64 - 1) / (256 * 64);
+    const unsigned grid = (unsigned)(blocks < 2048 ? (blocks ? blocks : 1) : 2048);
+    // pass 0: non-negative doubles from ~1e-60 up to ~1e240 have key halves 0xB000..0xEFFF
+    histogram_f64_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(
+        vol_dev, n, clip, has_clip, pass, (unsigned long long)prefix, pass == 0 ? 0xB000 : 0,
+        reinterpret_cast<unsigned long long*>(hist_dev));
+    EXA_CHECK_HIP(hipGetLastError());
+    return EXASPIM_OK;
+}
+
 template <int LAYOUT>
 static int gather_launch(const void* vol_dev, int32_t vox_dtype, const exaspim_block* blk,
                          const int32_t* starts_dev, int32_t n, const int32_t patch[3], double clip,
@@ -497,6 +554,7 @@ static int gather_launch(const void* vol_dev, int32_t vox_dtype, const exaspim_b
         case EXASPIM_VOX_U16: GATHER(EXASPIM_VOX_U16); break;
         case EXASPIM_VOX_I16: GATHER(EXASPIM_VOX_I16); break;
         case EXASPIM_VOX_F32: GATHER(EXASPIM_VOX_F32); break;
+        case EXASPIM_VOX_F64: GATHER(EXASPIM_VOX_F64); break;
         default:
             set_error("gather: unknown voxel dtype %d", vox_dtype);
             return EXASPIM_E_INVALID;

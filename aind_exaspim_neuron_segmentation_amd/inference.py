@@ -53,7 +53,11 @@ _VOX_CODES = {
     np.dtype(np.uint16): _native.VOX_U16,
     np.dtype(np.int16): _native.VOX_I16,
     np.dtype(np.float32): _native.VOX_F32,
+    np.dtype(np.float64): _native.VOX_F64,
 }
+_TORCH_VOXELS = {np.dtype(np.uint8): torch.uint8, np.dtype(np.uint16): torch.int16,
+                 np.dtype(np.int16): torch.int16, np.dtype(np.float32): torch.float32,
+                 np.dtype(np.float64): torch.float64}
 
 
 # --- Model Predictions ---
@@ -143,7 +147,7 @@ def predict(
             patch_shape=patch_shape, overlap=overlap, trim=trim, verbose=verbose,
             n_streams=n_streams, out_dtype=out_dtype,
         )
-    volume = DeviceVolume.from_array(img, device)
+    volume = DeviceVolume.from_array(img, device, clip=brightness_clip)
     plan = SlidingWindow(volume.shape, patch_shape, overlap, trim)
     n_channels = 3 if affinity_mode else 1
     with torch.cuda.device(device):
@@ -354,7 +358,10 @@ def load_model(path, affinity_mode=True, device="cuda", *, compute_dtype="fp32")
     device : str, optional
         Device to load the model onto. Default is "cuda" (the HIP device).
     compute_dtype : str, optional
-        "fp32" (default), "bf16" or "fp16" arithmetic of the network kernels.
+        "fp32" (default), "bf16" or "fp16" arithmetic of the network kernels, or
+        "auto": fp16 if this checkpoint, on the first batch of patches predict()
+        gives it, stays inside half range and within 1e-3 of its own float32
+        probabilities, float32 otherwise (UNet3D.resolve_compute_dtype).
 
     Returns
     -------
@@ -407,9 +414,9 @@ class DeviceVolume:
         Voxel dtype of the image as numpy sees it (what np.minimum and
         np.percentile of the reference operate on).
     storage_dtype : numpy.dtype
-        Dtype the voxels have in device memory (uint8, uint16, int16 or float32;
-        wider integers and float64 travel as float32 when every value is exactly
-        representable).
+        Dtype the voxels have in device memory (uint8, uint16, int16, float32 or
+        float64; wider integers and float64 travel as float32 when every value is
+        known to be exactly representable, as float64 otherwise).
     block : _native.Block
         Local dims / global origin / global shape.
     """
@@ -431,8 +438,10 @@ class DeviceVolume:
         self.block = _native.Block.make(tuple(tensor.shape), origin, self.shape)
 
     @classmethod
-    def from_array(cls, img, device):
-        """Uploads a numpy array (3-D to 5-D, leading axes of length 1)."""
+    def from_array(cls, img, device, clip=None):
+        """Uploads a numpy array (3-D to 5-D, leading axes of length 1); "clip" is the
+        brightness clip it will be used with (it can decide how wide integers and float64
+        voxels travel, see _device_voxel_dtype)."""
         if isinstance(img, DeviceVolume):
             return img
         if isinstance(img, torch.Tensor):
@@ -443,7 +452,7 @@ class DeviceVolume:
                 t = t[0]
             np_dtype = {
                 torch.uint8: np.uint8, torch.int16: np.int16, torch.float32: np.float32,
-                getattr(torch, "uint16", None): np.uint16,
+                torch.float64: np.float64, getattr(torch, "uint16", None): np.uint16,
             }.get(t.dtype)
             if np_dtype is None:
                 raise TypeError(f"tensor dtype {t.dtype} not supported")
@@ -455,15 +464,15 @@ class DeviceVolume:
             arr = arr[0]
         if arr.ndim != 3:
             raise ValueError(f"expected a 3-D image, got shape {np.shape(img)}")
-        storage, convert = _device_voxel_dtype(arr.dtype)
+        storage, convert = _device_voxel_dtype(arr.dtype, whole=arr, clip=clip)
         if storage not in _VOX_CODES:
             raise TypeError(_unsupported(arr.dtype))
         return cls(_carrier(convert(arr)).to(device), arr.dtype, storage_dtype=storage)
 
 
 def _unsupported(np_dtype):
-    return (f"voxel dtype {np_dtype} not supported (uint8, int8, uint16, int16, float32, and "
-            "int32 / uint32 / int64 / uint64 / float64 volumes whose values float32 holds exactly)")
+    return (f"voxel dtype {np_dtype} not supported (8-, 16-, 32- and 64-bit integers, float32 and "
+            "float64 are; 64-bit integers must be exactly representable in float64)")
 
 
 class SlidingWindow:
@@ -552,7 +561,8 @@ def _effective_clip(np_dtype, brightness_clip, storage_dtype=None):
         )
     clip = np.float64(brightness_clip)
     storage = np.dtype(storage_dtype) if storage_dtype is not None else _device_voxel_dtype(np_dtype)[0]
-    if storage == np.float32 and np.float64(np.float32(clip)) != clip:
+    if storage == np.float32 and np_dtype != np.float32 and np.float64(np.float32(clip)) != clip:
+        # (predict() sends such a volume as float64 instead: _device_voxel_dtype(..., clip=))
         raise NotImplementedError(
             f"brightness_clip {brightness_clip!r} is not a float32 number (the volume travels as float32)"
         )
@@ -561,6 +571,16 @@ def _effective_clip(np_dtype, brightness_clip, storage_dtype=None):
 
 def _histogram_into(hist, tensor, vox_code, clip, pass_index=0, prefix=0):
     """Adds the voxels of a device tensor to an int64 (65536,) device histogram."""
+    if vox_code == _native.VOX_F64:
+        _native.check(
+            _native.lib().exaspim_histogram_wide(
+                tensor.data_ptr(), vox_code, tensor.numel(),
+                float(clip) if clip is not None else 0.0, 1 if clip is not None else 0,
+                pass_index, int(prefix), hist.data_ptr(), _stream(tensor.device),
+            ),
+            "exaspim_histogram_wide",
+        )
+        return
     _native.check(
         _native.lib().exaspim_histogram(
             tensor.data_ptr(), vox_code, tensor.numel(),
@@ -585,6 +605,13 @@ def _key_to_f32(key):
     return np.array([bits], dtype=np.uint32).view(np.float32)[0]
 
 
+def _key_to_f64(key):
+    """Inverse of the order-preserving float64 key of the wide histogram kernel."""
+    key = int(key)
+    bits = (key & 0x7FFFFFFFFFFFFFFF) if key >> 63 else (~key & 0xFFFFFFFFFFFFFFFF)
+    return np.array([bits], dtype=np.uint64).view(np.float64)[0]
+
+
 def _percentiles_from_histograms(histogram, storage_dtype, percentiles, value_dtype=None, clip=None):
     """
     np.percentile of the clipped volume from 65536-bin histograms:
@@ -606,6 +633,27 @@ def _percentiles_from_histograms(histogram, storage_dtype, percentiles, value_dt
     if storage_dtype.kind in "ui":
         offset = 32768 if storage_dtype == np.int16 else 0
         stats = img_util.OrderStatistics(histogram(), lambda b: as_value(b - offset))
+    elif storage_dtype == np.float64:
+        # radix select on the order-preserving 64-bit key, 16 bits per level
+        levels = {}
+
+        def level(p, prefix):
+            if (p, prefix) not in levels:
+                levels[(p, prefix)] = img_util.OrderStatistics(histogram(p, prefix), lambda b: b)
+            return levels[(p, prefix)]
+
+        class _F64Stats:
+            n = level(0, 0).n
+
+            @staticmethod
+            def kth(k):
+                prefix, rank = 0, k
+                for p in range(4):
+                    b, rank = level(p, prefix).bin_of_rank(rank)
+                    prefix = (prefix << 16) | b
+                return as_value(_key_to_f64(prefix))
+
+        stats = _F64Stats()
     else:
         coarse = img_util.OrderStatistics(histogram(0), lambda b: b)
         fine = {}
@@ -776,6 +824,12 @@ def run_sliding_window(volume, model, plan, n_channels, batch_size, brightness_c
     workers = _worker_streams(device, n_streams) if n_streams > 1 else [main]
     for s in workers:
         s.wait_stream(main)  # volume, accumulator and starts are ready on the caller's stream
+    if isinstance(model, UNet3D) and model.needs_resolution():
+        # compute_dtype="auto": the first batch of real patches decides between fp16 and float32
+        probe = _get_batch_inputs(volume, starts_dev[:batch_size], plan.patch_shape, device, clip=clip,
+                                  mn=mn, mx=mx)
+        model.resolve_compute_dtype(probe)
+        del probe
     prepared_layout = None
     if isinstance(model, UNet3D) and os.environ.get("EXASPIM_PLAIN_GATHER") != "1":
         prepared_layout = model.input_layout(device)    # (EXASPIM_PLAIN_GATHER=1: tests hold the two paths to each other)
@@ -961,26 +1015,40 @@ class _ArraySource:
         return np.asarray(self.arr[z0:z1])
 
 
-def _device_voxel_dtype(np_dtype):
+def _device_voxel_dtype(np_dtype, whole=None, clip=None):
     """
-    Voxel dtype the kernels read for an image of "np_dtype", and the function that
-    converts a block to it. uint8 / uint16 / int16 / float32 travel as they are,
-    int8 as int16; 32- and 64-bit integers and float64 travel as float32 when
-    every value is exactly representable (the kernels evaluate the reference's
-    float64 arithmetic on the same numbers); anything else raises TypeError.
+    Voxel dtype the kernels read for an image of "np_dtype", and the function that converts a
+    block to it. uint8 / uint16 / int16 / float32 / float64 travel as they are, int8 as int16.
+    32- and 64-bit integers travel as float32 when the caller can show that every value is
+    exactly representable ("whole": the entire image as an in-memory array) -- half the bytes --
+    and as float64 otherwise (what the reference's arithmetic works in, img_util.py:526-531);
+    float64 images likewise go as float32 only when "whole" proves them float32-exact. A
+    brightness clip float32 cannot hold ("clip") sends them as float64 too. 64-bit integers that
+    float64 cannot hold raise TypeError.
     """
     np_dtype = np.dtype(np_dtype)
-    if np_dtype in _VOX_CODES:
-        return np_dtype, lambda block: block
     if np_dtype == np.int8:
         return np.dtype(np.int16), lambda block: block.astype(np.int16)
-    if np_dtype.kind in "iuf" and np_dtype.itemsize in (4, 8):
-        def to_f32(block):
-            as32 = block.astype(np.float32)
-            if not np.array_equal(as32.astype(np_dtype), block):
-                raise TypeError(f"{np_dtype} volume is not exactly representable in float32")
-            return as32
-        return np.dtype(np.float32), to_f32
+    if np_dtype.kind in "iuf" and np_dtype.itemsize in (4, 8) and np_dtype != np.float32:
+        clip_ok = clip is None or np.float64(np.float32(clip)) == np.float64(clip)
+        if whole is not None and clip_ok:
+            as32 = np.asarray(whole).astype(np.float32)
+            if np.array_equal(as32.astype(np_dtype), whole):
+                def to_f32(block):
+                    b32 = block.astype(np.float32)
+                    if not np.array_equal(b32.astype(np_dtype), block):
+                        raise TypeError(f"{np_dtype} volume is not exactly representable in float32")
+                    return b32
+                return np.dtype(np.float32), to_f32
+
+        def to_f64(block):
+            b64 = block.astype(np.float64)
+            if np_dtype.kind in "iu" and np_dtype.itemsize == 8 and not np.array_equal(b64.astype(np_dtype), block):
+                raise TypeError(f"{np_dtype} volume is not exactly representable in float64")
+            return b64
+        return np.dtype(np.float64), to_f64
+    if np_dtype in _VOX_CODES:
+        return np_dtype, lambda block: block
     return np_dtype, lambda block: block
 
 
@@ -1097,7 +1165,12 @@ def predict_streaming(
     else:
         src = _ArraySource(source if hasattr(source, "shape") else np.asarray(source))
         read_block, vshape, src_dtype = src, src.shape, src.dtype
-    vdtype, convert = _device_voxel_dtype(src_dtype)   # dtype in device memory
+    whole = None
+    if not callable(source) or hasattr(source, "shape"):
+        arr = read_block.arr
+        if isinstance(arr, np.ndarray) and not isinstance(arr, np.memmap):
+            whole = arr      # an in-memory array can show that float32 carries it exactly
+    vdtype, convert = _device_voxel_dtype(src_dtype, whole=whole, clip=brightness_clip)   # dtype in device memory
     if vdtype not in _VOX_CODES:
         raise TypeError(_unsupported(src_dtype))
     plan = SlidingWindow(vshape, patch_shape, overlap, trim)
@@ -1108,8 +1181,7 @@ def predict_streaming(
     ranges = _start_ranges(vshape, plan.patch_shape, plan.overlap)
     yx_starts = list(itertools.product(*ranges[1:]))
     z_starts = list(ranges[0]) if yx_starts else []
-    torch_dtype = {np.dtype(np.uint8): torch.uint8, np.dtype(np.uint16): torch.int16,
-                   np.dtype(np.int16): torch.int16, np.dtype(np.float32): torch.float32}[vdtype]
+    torch_dtype = _TORCH_VOXELS[vdtype]
     plane = H * W
 
     result = res4 = None

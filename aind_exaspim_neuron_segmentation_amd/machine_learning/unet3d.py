@@ -17,6 +17,7 @@ path -- calling the model with a CPU tensor raises.
 
 import ctypes
 import math
+import warnings
 
 import numpy as np
 import torch
@@ -95,13 +96,20 @@ class UNet3D(nn.Module):
         Factor that scales the number of channels in each layer. Default is 1.
     compute_dtype : str, optional
         "fp32" (exact fp32 matrix-core path, default), "bf16" or "fp16"
-        (16-bit activations and weights, fp32 accumulation).
+        (16-bit activations and weights, fp32 accumulation), or "auto": fp16
+        if THIS checkpoint stays inside half range and within 1e-3 of its own
+        float32 result on the first batch of real patches it sees, float32
+        otherwise (resolve_compute_dtype; until then the model runs float32).
     """
+
+    AUTO_TOLERANCE = 1e-3    # north_star's bar on the probabilities
+    AUTO_HEADROOM = 2.0      # float32 activations must stay below 65504 / headroom
+    HALF_MAX = 65504.0
 
     def __init__(self, output_channels=1, trilinear=True, width_multiplier=1,
                  compute_dtype="fp32"):
         super().__init__()
-        if compute_dtype not in _native.DTYPE_CODES:
+        if compute_dtype != "auto" and compute_dtype not in _native.DTYPE_CODES:
             raise ValueError(f"unknown compute_dtype {compute_dtype!r}")
         self.channels = unet_channels(width_multiplier)
         self.trilinear = trilinear
@@ -121,9 +129,10 @@ class UNet3D(nn.Module):
             _attach(self, f"{prefix}.3", _ConvParams(cmid, cout, 3))
             _attach(self, f"{prefix}.4", _NormParams(cout))
         _attach(self, "outc.conv", _ConvParams(head_in, head_out, 1))
-        self._engine = None       # opaque exaspim_unet*
-        self._engine_key = None
-        self._packed = None       # device image of the packed weights
+        self._engines = {}        # compute dtype -> {"handle": exaspim_unet*, "packed": device image, "key": state}
+        self._resolved = None     # what "auto" decided ("fp16" / "fp32"), None until the first batch
+        self._resolved_key = None # parameter state that decision was taken for
+        self.auto_report = None   # the measurements behind that decision (resolve_compute_dtype)
         self._workspace = None
 
     # ---- engine management -------------------------------------------------
@@ -136,18 +145,29 @@ class UNet3D(nn.Module):
             chunks.append(value.detach().to("cpu", torch.float32).reshape(-1))
         return torch.cat(chunks).contiguous().numpy()
 
-    def _state_key(self, device):
+    def _state_key(self, device, dtype):
         tensors = list(self.parameters()) + list(self.buffers())
         return (
-            str(device), self.compute_dtype,
+            str(device), dtype,
             tuple((t.data_ptr(), t._version) for t in tensors),
         )
 
+    def active_dtype(self):
+        """The compute dtype forward passes run in right now ("auto": float32 until resolved)."""
+        if self.compute_dtype == "auto":
+            return self._resolved or "fp32"
+        return self.compute_dtype
+
+    @property
+    def _engine(self):
+        """Opaque exaspim_unet* of the active compute dtype (None before the first use)."""
+        entry = self._engines.get(self.active_dtype())
+        return entry["handle"] if entry else None
+
     def _release_engine(self):
-        if self._engine is not None:
-            _native.lib().exaspim_unet_destroy(self._engine)
-        self._engine = None
-        self._engine_key = None
+        for entry in self._engines.values():
+            _native.lib().exaspim_unet_destroy(entry["handle"])
+        self._engines = {}
 
     def __del__(self):
         try:
@@ -155,14 +175,20 @@ class UNet3D(nn.Module):
         except Exception:
             pass
 
-    def _ensure_engine(self, device):
-        key = self._state_key(device)
-        if self._engine is not None and key == self._engine_key:
-            return
-        self._release_engine()
+    def _ensure_engine(self, device, dtype=None):
+        """Packs the current parameters for "dtype" (default: the active one) and binds an engine
+        to them; a no-op while neither the parameters nor the device changed."""
+        dtype = dtype or self.active_dtype()
+        key = self._state_key(device, dtype)
+        entry = self._engines.get(dtype)
+        if entry is not None and key == entry["key"]:
+            return entry["handle"]
+        if entry is not None:
+            _native.lib().exaspim_unet_destroy(entry["handle"])
+            del self._engines[dtype]
         lib = _native.lib()
         ch = _native.channels_array(self.channels)
-        code = _native.DTYPE_CODES[self.compute_dtype]
+        code = _native.DTYPE_CODES[dtype]
         if not self.trilinear:
             code |= _native.UP_CONVT
         params = self._canonical_params()
@@ -182,18 +208,18 @@ class UNet3D(nn.Module):
             ),
             "exaspim_unet_pack_weights",
         )
-        self._packed = torch.from_numpy(packed).to(device)
+        packed_dev = torch.from_numpy(packed).to(device)
         handle = ctypes.c_void_p()
         index = device.index if device.index is not None else torch.cuda.current_device()
         _native.check(
             lib.exaspim_unet_create(
-                ch, self.output_channels, code, index, self._packed.data_ptr(), nbytes,
+                ch, self.output_channels, code, index, packed_dev.data_ptr(), nbytes,
                 ctypes.byref(handle),
             ),
             "exaspim_unet_create",
         )
-        self._engine = handle
-        self._engine_key = key
+        self._engines[dtype] = {"handle": handle, "packed": packed_dev, "key": key}
+        return handle
 
     def _get_workspace(self, n, d, h, w, device, stream):
         """Scratch buffer for one forward; one per HIP stream so that batches in
@@ -212,6 +238,111 @@ class UNet3D(nn.Module):
             ws = torch.empty(need, dtype=torch.uint8, device=device)
             self._workspace[key] = ws
         return ws
+
+    # ---- 16-bit safety: ranges and deviation on real patches -----------------
+    def _forward_absmax(self, x, dtype):
+        """sigmoid(forward(x)) with the engine of "dtype" plus the largest |activation| every
+        layer stored (exaspim_unet_forward_absmax)."""
+        device = x.device
+        n, _, d, h, w = x.shape
+        with torch.cuda.device(device):
+            handle = self._ensure_engine(device, dtype)
+            stream = torch.cuda.current_stream(device).cuda_stream
+            need = _native.lib().exaspim_unet_workspace_bytes(handle, n, d, h, w)
+            if need == 0:
+                raise RuntimeError("Sizes of tensors must match: " + _native.last_error())
+            ws = torch.empty(need, dtype=torch.uint8, device=device)
+            out = torch.empty((n, self.output_channels, d, h, w), dtype=torch.float32, device=device)
+            absmax = torch.zeros(22, dtype=torch.float32, device=device)   # EXASPIM_ABSMAX_SLOTS
+            _native.check(
+                _native.lib().exaspim_unet_forward_absmax(
+                    handle, x.data_ptr(), out.data_ptr(), n, d, h, w, 1, absmax.data_ptr(),
+                    ws.data_ptr(), ws.numel(), stream),
+                "exaspim_unet_forward_absmax",
+            )
+        return out, absmax
+
+    def fp16_report(self, x):
+        """
+        Measures, on a batch of real patches, what IEEE-half storage does to THIS checkpoint:
+        the float32 engine's largest |activation| per layer (half stores saturate at 65504), the
+        fp16 engine's (65504 there = a store saturated) and the largest deviation of the fp16
+        probabilities from the float32 ones.
+
+        Parameters
+        ----------
+        x : torch.Tensor
+            float32 (B, 1, D, H, W) network inputs on the HIP device (normalised patches, as
+            inference._get_batch_inputs builds them).
+
+        Returns
+        -------
+        dict
+            "max_abs_diff", "fp32_absmax" / "fp16_absmax" (per layer: inc.0, the 17 MFMA
+            convolutions, the 4 transposed convolutions), "fp32_peak", "saturated", "finite".
+        """
+        if x.dim() != 5 or x.shape[1] != 1 or not x.is_cuda:
+            raise RuntimeError(f"expected a (B, 1, D, H, W) tensor on a HIP device, got {tuple(x.shape)} on {x.device}")
+        x = x.to(torch.float32).contiguous()
+        p32, r32 = self._forward_absmax(x, "fp32")
+        p16, r16 = self._forward_absmax(x, "fp16")
+        diff = float((p16 - p32).abs().max().item())
+        r32, r16 = r32.cpu().numpy(), r16.cpu().numpy()
+        return {
+            "max_abs_diff": diff,
+            "fp32_absmax": [float(v) for v in r32],
+            "fp16_absmax": [float(v) for v in r16],
+            "fp32_peak": float(np.nanmax(r32)) if np.isfinite(r32).any() else float("nan"),
+            "saturated": bool((r16 >= self.HALF_MAX).any()),
+            "finite": bool(np.isfinite(r32).all() and np.isfinite(r16).all() and np.isfinite(diff)),
+            "patches": int(x.shape[0]),
+        }
+
+    def needs_resolution(self):
+        """True for compute_dtype="auto" before resolve_compute_dtype has run on the CURRENT
+        parameters (loading new weights or moving the model asks for a new decision)."""
+        if self.compute_dtype != "auto":
+            return False
+        if self._resolved is not None and self._resolved_key != self._state_key(
+                next(self.parameters()).device, "auto"):
+            self._resolved, self.auto_report = None, None
+        return self._resolved is None
+
+    def resolve_compute_dtype(self, x):
+        """
+        compute_dtype="auto": decides between fp16 and float32 from fp16_report(x) on the first
+        batch of real patches (predict() calls this) -- fp16 if nothing saturated, the float32
+        activations keep a factor AUTO_HEADROOM below 65504 and the probabilities agree within
+        AUTO_TOLERANCE; float32, with a warning, otherwise. The reference runs any checkpoint in
+        float32 (inference.py:400-424); its trainer uses fp16 autocast (train.py:218-223), so
+        trained checkpoints normally pass.
+
+        Returns
+        -------
+        str
+            "fp16" or "fp32" (also kept in active_dtype(); the report in auto_report).
+        """
+        if self.compute_dtype != "auto":
+            return self.compute_dtype
+        rep = self.fp16_report(x)
+        reasons = []
+        if not rep["finite"]:
+            reasons.append("non-finite activations")
+        if rep["saturated"]:
+            reasons.append("a half-precision store saturated at 65504")
+        if rep["fp32_peak"] * self.AUTO_HEADROOM > self.HALF_MAX:
+            reasons.append(f"float32 activations reach {rep['fp32_peak']:.4g} (less than a factor "
+                           f"{self.AUTO_HEADROOM:g} below 65504)")
+        if not rep["max_abs_diff"] <= self.AUTO_TOLERANCE:
+            reasons.append(f"fp16 probabilities deviate by {rep['max_abs_diff']:.3g} > {self.AUTO_TOLERANCE:g}")
+        self._resolved = "fp32" if reasons else "fp16"
+        self._resolved_key = self._state_key(x.device, "auto")
+        rep["chosen"], rep["reasons"] = self._resolved, reasons
+        self.auto_report = rep
+        if reasons:
+            warnings.warn("UNet3D(compute_dtype='auto'): falling back to float32 -- " + "; ".join(reasons),
+                          RuntimeWarning, stacklevel=2)
+        return self._resolved
 
     # ---- forward -----------------------------------------------------------
     def run(self, x, apply_sigmoid=False, out=None, trim=0):

@@ -455,7 +455,7 @@ class DeviceShardOps:
     # -- voxels
     def storage(self, src_dtype):
         """(voxel dtype in device memory, host conversion) for an image dtype."""
-        vdtype, convert = self.inf._device_voxel_dtype(src_dtype)
+        vdtype, convert = self.inf._device_voxel_dtype(src_dtype, clip=self.brightness_clip)
         if vdtype not in self.inf._VOX_CODES:
             raise TypeError(self.inf._unsupported(src_dtype))
         return vdtype, convert
@@ -464,9 +464,7 @@ class DeviceShardOps:
         return self.inf._carrier(convert(block)).to(self.device, non_blocking=True)
 
     def empty_voxels(self, dims, vdtype):
-        torch_dtype = {np.dtype(np.uint8): torch.uint8, np.dtype(np.uint16): torch.int16,
-                       np.dtype(np.int16): torch.int16, np.dtype(np.float32): torch.float32}[np.dtype(vdtype)]
-        return torch.empty(tuple(dims), dtype=torch_dtype, device=self.device)
+        return torch.empty(tuple(dims), dtype=self.inf._TORCH_VOXELS[np.dtype(vdtype)], device=self.device)
 
     def effective_clip(self, src_dtype, vdtype):
         return self.inf._effective_clip(src_dtype, self.brightness_clip, vdtype)

@@ -32,8 +32,9 @@
 extern "C" {
 #endif
 
-/* 3: exaspim_export_f16 added (entry points are only ever added within a major line) */
-#define EXASPIM_ABI_VERSION 4
+/* 3: exaspim_export_f16 added (entry points are only ever added within a major line);
+ * 5: exaspim_unet_forward_absmax, exaspim_histogram_wide (EXASPIM_VOX_F64) */
+#define EXASPIM_ABI_VERSION 5
 
 /* error codes */
 #define EXASPIM_OK 0
@@ -59,6 +60,7 @@ extern "C" {
 #define EXASPIM_VOX_U16 1
 #define EXASPIM_VOX_I16 2
 #define EXASPIM_VOX_F32 3
+#define EXASPIM_VOX_F64 4 /* float64, and wider integers converted on the host: what float32 cannot carry */
 
 typedef struct exaspim_unet exaspim_unet; /* opaque engine handle */
 
@@ -155,6 +157,21 @@ int exaspim_unet_forward_prepared(exaspim_unet* h, const void* x_prepared_dev, f
                                   int32_t apply_sigmoid, int32_t trim, void* workspace_dev,
                                   size_t workspace_bytes, void* stream);
 
+/* Range probe for the 16-bit storage modes. The reference loads ANY trained state_dict
+ * (inference.py:400-424) and runs it in float32; IEEE-half storage holds |v| <= 65504 (stores
+ * saturate there) with 11 significant bits. This is exaspim_unet_forward (nothing fused away,
+ * nothing trimmed) that also raises absmax_dev[0] (inc.0), absmax_dev[1 + i] (i-th MFMA
+ * convolution, the order of exaspim_unet_timing_begin's mask) and, with EXASPIM_UP_CONVT,
+ * absmax_dev[18 + j] (up(j+1).up) to the largest |activation| the layer stored, as float32
+ * (caller-zeroed float[EXASPIM_ABSMAX_SLOTS]; a NaN is reported as NaN). Run on a float32
+ * engine it gives the true ranges of a checkpoint on real patches; on an f16 engine a value of
+ * 65504 means a store saturated. UNet3D(compute_dtype="auto") decides with it on the first batch. */
+#define EXASPIM_ABSMAX_SLOTS 22
+int exaspim_unet_forward_absmax(exaspim_unet* h, const float* x_dev, float* out_dev,
+                                int32_t n, int32_t d, int32_t hgt, int32_t w,
+                                int32_t apply_sigmoid, float* absmax_dev, void* workspace_dev,
+                                size_t workspace_bytes, void* stream);
+
 /* Measurement hooks (bench.py's roofline leg). timing_begin arms HIP-event
  * timing, on the launch stream, of the MFMA convolutions whose bit is set in
  * conv_mask (bit i = i-th 3x3x3 conv after inc.0 in state_dict order: inc.3,
@@ -182,6 +199,15 @@ int exaspim_unet_timing_read(exaspim_unet* h, double ms_sum[17], int32_t count[1
 int exaspim_histogram(const void* vol_dev, int32_t vox_dtype, size_t n,
                       double clip, int32_t has_clip, int32_t pass,
                       uint32_t prefix, uint64_t* hist_dev, void* stream);
+
+/* The same for EXASPIM_VOX_F64 volumes (the reference takes ANY numeric array and works in
+ * float64, inference.py:79-80, img_util.py:526-531): voxels are binned by an order-preserving
+ * 64-bit key, 16 bits per pass -- pass p (0..3) bins key bits [48 - 16p, 64 - 16p) of the voxels
+ * whose key bits above that field equal "prefix" (0 for pass 0). The clip is a float64 itself,
+ * so min(voxel, clip) is exact. Four passes per order statistic give it exactly. */
+int exaspim_histogram_wide(const void* vol_dev, int32_t vox_dtype, size_t n,
+                           double clip, int32_t has_clip, int32_t pass,
+                           uint64_t prefix, uint64_t* hist_dev, void* stream);
 
 /* Builds a batch of network inputs: for patch i with global start
  * starts_dev[3*i..3*i+2] (int32 z,y,x), out[i] (float32 patch[0] x patch[1] x

@@ -234,3 +234,80 @@ def test_fp16_mode_has_headroom_and_saturates(dev, oracle):
             sd_all[k] = sd_all[k] * 8.0
     out = model_with(sd_all).run(x.to(dev), apply_sigmoid=True).cpu().numpy()
     assert np.isfinite(out).all() and out.min() >= 0.0 and out.max() <= 1.0
+
+
+def test_auto_compute_dtype_checks_the_checkpoint_on_real_patches(dev, oracle, golden, tmp_path):
+    """compute_dtype="auto" (load_model accepts it): the first batch predict() gathers runs through
+    the float32 and the fp16 engine with a range probe (exaspim_unet_forward_absmax).
+    (1) The seeded network passes: fp16 is chosen, the report shows the deviation (< 1e-3) and
+        per-layer ranges far below 65504, and predict() equals the explicit fp16 model bit for bit.
+    (2) A checkpoint whose BatchNorm scales are all x8 (activations grow 8x per layer) saturates
+        half precision: auto falls back to float32 WITH a warning, and its predict() equals the
+        float32 model's bit for bit -- where the plain fp16 engine returns something else.
+    (3) The probe's ranges are the oracle's: max |activation| of the stored layers, float32 engine."""
+    import warnings
+
+    from aind_exaspim_neuron_segmentation_amd import inference
+    from aind_exaspim_neuron_segmentation_amd.machine_learning.unet3d import UNet3D
+
+    kw = dict(patch_shape=(32, 32, 32), overlap=(8, 8, 8), trim=4, batch_size=4, verbose=False)
+    vol = synthetic.synth_volume((56, 56, 56), seed=5)
+
+    def save(sd, name):
+        path = tmp_path / name
+        torch.save({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, path)
+        return str(path)
+
+    sd = synthetic.synth_state_dict(3, 1, seed=1)
+    # (1) passes
+    auto = inference.load_model(save(sd, "ok.pth"), compute_dtype="auto")
+    assert auto.needs_resolution() and auto.active_dtype() == "fp32"
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        got = inference.predict(vol, auto, **kw)
+    rep = auto.auto_report
+    assert auto.active_dtype() == "fp16" and rep["chosen"] == "fp16" and not rep["reasons"]
+    assert 0 < rep["max_abs_diff"] < 1e-3 and not rep["saturated"] and rep["fp32_peak"] < 100
+    assert len(rep["fp32_absmax"]) == 22 and all(v > 0 for v in rep["fp32_absmax"][:18])
+    assert rep["fp32_absmax"][18:] == [0.0] * 4                   # no transposed convolutions here
+    fp16 = inference.load_model(save(sd, "ok2.pth"), compute_dtype="fp16")
+    np.testing.assert_array_equal(got, inference.predict(vol, fp16, **kw))
+
+    # (3) the probe against the oracle's intermediates (float32 engine, stored layers)
+    x = inference._get_batch_inputs(inference.DeviceVolume.from_array(vol, dev),
+                                    torch.tensor([[0, 0, 0], [24, 24, 24]], dtype=torch.int32, device=dev),
+                                    (32, 32, 32), dev, clip=np.uint16(1000), mn=19.0, mx=1000.0)
+    _, feats = oracle.unet_forward(x.cpu(), oracle.OracleModel(sd).sd, return_intermediates=True)
+    _, r32 = auto._forward_absmax(x, "fp32")
+    r32 = r32.cpu().numpy()
+    # conv index (1 + i) of the second conv of each block: x1..x5 = inc.3, down1.3 .. down4.3; y1..y4 = up1.3 .. up4.3
+    for name, slot in (("x1", 1), ("x2", 3), ("x3", 5), ("x4", 7), ("x5", 9), ("y1", 11), ("y2", 13), ("y3", 15), ("y4", 17)):
+        want = float(feats[name].abs().max())
+        assert abs(r32[slot] - want) <= 1e-4 * want, (name, r32[slot], want)
+
+    # (2) a checkpoint that does not fit half precision
+    sd_all = synthetic.synth_state_dict(3, 1, seed=1)
+    for k in sd_all:
+        if k.endswith((".1.weight", ".4.weight")):
+            sd_all[k] = sd_all[k] * 8.0
+    bad = inference.load_model(save(sd_all, "bad.pth"), compute_dtype="auto")
+    with pytest.warns(RuntimeWarning, match="falling back to float32"):
+        got_bad = inference.predict(vol, bad, **kw)
+    assert bad.active_dtype() == "fp32" and bad.auto_report["saturated"] and bad.auto_report["reasons"]
+    f32 = inference.load_model(save(sd_all, "bad2.pth"))
+    np.testing.assert_array_equal(got_bad, inference.predict(vol, f32, **kw))
+    h16 = inference.load_model(save(sd_all, "bad3.pth"), compute_dtype="fp16")
+    assert np.abs(inference.predict(vol, h16, **kw) - got_bad).max() > 1e-3
+    # new weights: the decision is taken again
+    bad.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        np.testing.assert_array_equal(inference.predict(vol, bad, **kw), got)
+    assert bad.active_dtype() == "fp16"
+    # the transposed-convolution variant reports its four extra layers
+    sdt = synthetic.synth_state_dict(3, 1, seed=2, trilinear=False)
+    mt = UNet3D(output_channels=3, trilinear=False, compute_dtype="auto")
+    mt.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sdt.items()})
+    mt.to(dev).eval()
+    rept = mt.fp16_report(x)
+    assert all(v > 0 for v in rept["fp32_absmax"][18:]) and rept["max_abs_diff"] < 1e-3

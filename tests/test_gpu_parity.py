@@ -584,7 +584,8 @@ def test_predict_voxel_dtypes_vs_oracle(dev, oracle, name, clip):
                                        ("i32_fractional_clip", 800.5)])
 def test_predict_takes_the_dtypes_the_reference_takes(dev, oracle, name, clip):
     """inference.py:79-80 runs on any numeric array: wider integers and float64 travel to
-    the device as float32 (exactly representable values), int8 as int16, and a clip that
+    the device as float32 when the array shows that float32 holds every value (as float64
+    otherwise, next test), int8 as int16, and a clip that
     makes np.minimum promote an integer image to float64 is evaluated the same way
     (voxels above it take the clip's own, fractional, value)."""
     from aind_exaspim_neuron_segmentation_amd import inference
@@ -617,16 +618,60 @@ def test_predict_takes_the_dtypes_the_reference_takes(dev, oracle, name, clip):
     assert (mn, mx) == (ref[0], ref[1])
 
 
-def test_predict_rejects_what_float32_cannot_carry(dev):
+@pytest.mark.parametrize("name,clip", [
+    ("f64_fractions", 1000), ("f64_fractions", 123.456789), ("f64_fractions", None),
+    ("i64_beyond_float32", 1 << 41), ("u32_beyond_float32", 4_000_000_001), ("i32_irrational_clip", 0.1 + 900),
+    ("f64_negative", 3.0),
+])
+def test_predict_takes_what_float32_cannot_carry(dev, oracle, name, clip):
+    """The reference takes ANY numeric array and works in float64 (inference.py:79-80,
+    img_util.py:526-531). Values float32 cannot hold -- fractions of a float64 image, integers
+    beyond 2^24, a clip that is no float32 number -- travel to the device as float64: four-pass
+    histogram on a 64-bit key (exaspim_histogram_wide), float64 gather. Percentiles equal numpy's
+    bit for bit, predict() the oracle's."""
+    from aind_exaspim_neuron_segmentation_amd import inference
+
+    base = _volumes()["u16"].astype(np.float64)  # (40, 48, 56), values 0..1999
+    rng = np.random.default_rng(5)
+    vol = {
+        "f64_fractions": base + rng.random(base.shape),                       # 52-bit fractions
+        "i64_beyond_float32": base.astype(np.int64) * ((1 << 30) + 1) + 7,    # up to 2^41, odd
+        "u32_beyond_float32": (base.astype(np.uint32) * 2_100_003 + 17),      # up to 4.2e9
+        "i32_irrational_clip": base.astype(np.int32) - 300,
+        "f64_negative": rng.normal(0.0, 2.0, base.shape),
+    }[name]
+    model, sd = make_model(dev)
+    kw = dict(batch_size=4, patch_shape=(32, 32, 32), overlap=(16, 8, 8), trim=4,
+              brightness_clip=clip, normalization_percentiles=(2, 98.5))
+    dv = inference.DeviceVolume.from_array(vol, dev, clip=clip)
+    assert dv.storage_dtype == np.float64 and dv.tensor.dtype == torch.float64
+    mn, mx = inference.volume_percentiles(dv, clip, (2, 98.5))
+    ref = np.percentile(np.minimum(vol, clip) if clip is not None else vol, (2, 98.5))
+    assert (mn, mx) == (ref[0], ref[1])
+    want = oracle.predict(vol, oracle.OracleModel(sd), **kw) if clip is not None else None
+    got = inference.predict(vol, model, verbose=False, **kw)
+    if want is None:        # the oracle (like the reference) always clips: compare through a clip above every voxel
+        want = oracle.predict(vol, oracle.OracleModel(sd), **dict(kw, brightness_clip=1e300))
+    err = np.abs(got - want).max()
+    print(f"predict {name}, clip {clip}: max|diff| = {err:.3e}")
+    assert err < 1e-5
+    np.testing.assert_array_equal(got == 0, want == 0)
+    # the device-resident route and a chunked source (no knowledge of the values: float64 carrier)
+    t = inference.predict(vol, model, verbose=False, return_device_tensor=True, **kw)
+    np.testing.assert_array_equal(t.cpu().numpy(), got)
+    got2 = inference.predict_streaming(lambda z0, z1: vol[z0:z1], model, verbose=False, shape=vol.shape,
+                                       dtype=vol.dtype, **kw)
+    np.testing.assert_array_equal(got2, got)
+
+
+def test_predict_rejects_what_no_float_can_carry(dev):
     from aind_exaspim_neuron_segmentation_amd import inference
 
     model, _ = make_model(dev)
     vol = _volumes()["u16"]
     kw = dict(patch_shape=(32, 32, 32), overlap=(8, 8, 8), trim=4, verbose=False)
-    with pytest.raises(TypeError, match="not exactly representable"):
-        inference.predict(vol.astype(np.int64) + ((1 << 40) + 1), model, **kw)
-    with pytest.raises(TypeError, match="not exactly representable"):
-        inference.predict(vol.astype(np.float64) + 1e-9, model, **kw)
+    with pytest.raises(TypeError, match="not exactly representable in float64"):
+        inference.predict(vol.astype(np.int64) + ((1 << 60) + 1), model, **kw)
     with pytest.raises(TypeError, match="not supported"):
         inference.predict(vol.astype(np.complex64), model, **kw)
     with pytest.raises(OverflowError):          # numpy's own refusal (inference.py:79)

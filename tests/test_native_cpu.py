@@ -33,7 +33,7 @@ def test_header_symbols_are_exported(lib):
     assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.exaspim_abi_version() == 4
+    assert lib.exaspim_abi_version() == 5
 
 
 def test_param_count_matches_state_dict(lib):
@@ -306,13 +306,32 @@ def test_dtype_rules_and_fractional_clip_percentiles_on_the_host():
     for dt, want in ((np.uint8, np.uint8), (np.int8, np.int16), (np.uint16, np.uint16), (np.int16, np.int16),
                      (np.float32, np.float32), (np.int32, np.float32), (np.uint32, np.float32),
                      (np.int64, np.float32), (np.uint64, np.float32), (np.float64, np.float32)):
-        storage, convert = inf._device_voxel_dtype(dt)
-        assert storage == np.dtype(want)
         block = (np.arange(24).reshape(2, 3, 4) % 7).astype(dt)
+        # the whole image is at hand and float32 holds it: the narrow carrier
+        storage, convert = inf._device_voxel_dtype(dt, whole=block)
+        assert storage == np.dtype(want)
         np.testing.assert_array_equal(convert(block).astype(np.float64), block.astype(np.float64))
-    with pytest.raises(TypeError):
-        inf._device_voxel_dtype(np.int64)[1](np.array([[[(1 << 40) + 1]]], dtype=np.int64))
+        # nothing known about the values (a chunked source): wide dtypes travel as float64
+        storage, convert = inf._device_voxel_dtype(dt)
+        assert storage == (np.dtype(np.float64) if np.dtype(dt).itemsize >= 4 and dt != np.float32 else np.dtype(want))
+        np.testing.assert_array_equal(convert(block).astype(np.float64), block.astype(np.float64))
+    # values float32 cannot hold: float64 carrier (the reference works in float64, img_util.py:526-531)
+    wide = np.array([[[(1 << 40) + 1, 3]]], dtype=np.int64)
+    storage, convert = inf._device_voxel_dtype(np.int64, whole=wide)
+    assert storage == np.dtype(np.float64) and convert(wide)[0, 0, 0] == float((1 << 40) + 1)
+    frac = np.array([[[0.1, 0.25]]])
+    assert inf._device_voxel_dtype(np.float64, whole=frac)[0] == np.dtype(np.float64)
+    assert inf._device_voxel_dtype(np.float64, whole=frac * 0 + 0.25)[0] == np.dtype(np.float32)
+    # ... and so does a clip float32 cannot hold, whatever the values
+    assert inf._device_voxel_dtype(np.int32, whole=np.zeros((1, 1, 2), np.int32), clip=0.1)[0] == np.dtype(np.float64)
+    with pytest.raises(TypeError):      # beyond 2^53 float64 is not exact either
+        inf._device_voxel_dtype(np.int64)[1](np.array([[[(1 << 60) + 1]]], dtype=np.int64))
     assert inf._device_voxel_dtype(np.complex64)[0] not in inf._VOX_CODES
+    # the order-preserving 64-bit key of the wide histogram and its inverse
+    for v in (0.0, -0.0, 1.0, -1.0, 0.1, 1e300, -1e-300, 1000.5):
+        u = int(np.array([v]).view(np.uint64)[0])
+        key = (~u & 0xFFFFFFFFFFFFFFFF) if u >> 63 else (u | (1 << 63))
+        assert inf._key_to_f64(key) == v and np.signbit(inf._key_to_f64(key)) == np.signbit(v)
 
     assert inf._effective_clip(np.uint16, 1000) == (np.uint16(1000), np.dtype(np.uint16))
     assert inf._effective_clip(np.uint16, None) == (None, np.dtype(np.uint16))
@@ -320,8 +339,9 @@ def test_dtype_rules_and_fractional_clip_percentiles_on_the_host():
     assert inf._effective_clip(np.float32, 123.5) == (np.float32(123.5), np.dtype(np.float32))
     with pytest.raises(OverflowError):
         inf._effective_clip(np.uint8, 1000)
-    with pytest.raises(NotImplementedError):      # int32 travels as float32; 0.1 is not a float32 number
-        inf._effective_clip(np.int32, 0.1)
+    with pytest.raises(NotImplementedError):      # an int32 image forced onto the float32 carrier; 0.1 is not a float32 number
+        inf._effective_clip(np.int32, 0.1, np.float32)
+    assert inf._effective_clip(np.int32, 0.1, np.float64) == (np.float64(0.1), np.dtype(np.float64))
 
     vol = synthetic.synth_volume((24, 20, 28), seed=5)
     for clip in (1000.5, 37.25, 5000.75):
@@ -330,6 +350,42 @@ def test_dtype_rules_and_fractional_clip_percentiles_on_the_host():
         c, vdt = inf._effective_clip(vol.dtype, clip)
         got = inf._percentiles_from_histograms(lambda *a: hist, vol.dtype, (1, 99.9), vdt, c)
         np.testing.assert_array_equal(np.array(got), np.percentile(np.minimum(vol, clip), (1, 99.9)))
+
+
+def test_float64_percentiles_from_four_16_bit_passes_on_the_host():
+    """np.percentile of a float64 (or wide-integer) volume from the wide histogram's passes
+    (exaspim_histogram_wide: 16 bits of an order-preserving 64-bit key per pass), emulated here
+    with numpy: equal to numpy bit for bit, clip or no clip, negative values, ties."""
+    from aind_exaspim_neuron_segmentation_amd import inference as inf
+
+    rng = np.random.default_rng(11)
+
+    def passes(vol64, clip):
+        v = np.minimum(vol64, clip) if clip is not None else vol64
+        u = v.view(np.uint64)
+        key = np.where(u >> np.uint64(63) != 0, ~u, u | np.uint64(1 << 63))
+        calls = []
+
+        def histogram(p=0, prefix=0):
+            calls.append((p, prefix))
+            k = key if p == 0 else key[(key >> np.uint64(64 - 16 * p)) == np.uint64(prefix)]
+            return np.bincount(((k >> np.uint64(48 - 16 * p)) & np.uint64(0xFFFF)).astype(np.int64), minlength=65536)
+        return histogram, calls
+
+    cases = [
+        (rng.normal(500.0, 300.0, 4000), 1000.0, np.float64, (1, 99.9)),
+        (rng.normal(0.0, 1e-3, 3000), None, np.float64, (0, 100)),
+        (np.round(rng.normal(0, 3, 5000)), 2.5, np.float64, (5, 50)),                 # ties, fractional clip
+        (rng.integers(-(1 << 40), 1 << 40, 2000).astype(np.float64), None, np.int64, (1, 99.9)),   # wide integers
+        (rng.integers(0, 1 << 31, 2000).astype(np.float64), 1 << 30, np.uint32, (2.5, 97.5)),
+    ]
+    for vol64, clip, value_dtype, pcts in cases:
+        histogram, calls = passes(np.ascontiguousarray(vol64), clip)
+        got = inf._percentiles_from_histograms(histogram, np.float64, pcts, value_dtype, clip)
+        img = vol64.astype(value_dtype)
+        want = np.percentile(np.minimum(img, clip) if clip is not None else img, pcts)
+        np.testing.assert_array_equal(np.array(got), want)
+        assert calls[0] == (0, 0) and all(p <= 3 for p, _ in calls) and len(calls) <= 1 + 3 * 4
 
 
 def test_sliding_window_raises_where_the_reference_stitch_loop_raises():
