@@ -1299,6 +1299,11 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
     }
 }
 
+// ---- measured-and-not-adopted kernels ------------------------------------
+// conv3x3x3_zpair and conv3x3x3_t16 are compiled only with -DEXASPIM_VARIANTS (make variant
+// NAME=variants VFLAGS=-DEXASPIM_VARIANTS: tools/ and tests/test_gpu_parity.py's variant test load that
+// build through EXASPIM_LIB); the product library carries neither them nor their switches.
+#ifdef EXASPIM_VARIANTS
 // ---- conv3x3x3_zpair: the z-column kernel on v_mfma_f32_16x16x32 (16-bit modes) ----------
 // Under the package power cap the 16x16x32 shape sustains ~15 % more FLOP/s than 32x32x16
 // at equal operand traffic (tools/mfma_shape.hip). Its K is 32: with
@@ -1998,6 +2003,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3x3_t16(ConvArgs a, int tiles_z,
     }
 }
 
+#endif  // EXASPIM_VARIANTS
+
 #ifdef EXASPIM_TRACE
 int g_variant = 0;   // tools/conv_trace.hip: 3/5/6 = operand prefetch distance, +10 = one tile per workgroup
 #endif
@@ -2039,6 +2046,7 @@ static int launch_zpipe(const ConvArgs& a, hipStream_t stream) {
     return EXASPIM_OK;
 }
 
+#ifdef EXASPIM_VARIANTS
 template <typename Tag, int TZ, int D, int HEAD = 0, bool POOL = false>
 static int launch_zpair(const ConvArgs& a, hipStream_t stream) {
     constexpr int TY = 8, TX = 16, MINW = 2;
@@ -2089,6 +2097,8 @@ static bool paired_enabled() {
     }
     return on != 0;
 }
+
+#endif  // EXASPIM_VARIANTS
 
 // Split-K reduction: adds the float32 partial sums of the chunk ranges in range order, then
 // bias, LeakyReLU and the conversion, and writes four channels of one voxel in the blocked
@@ -2226,16 +2236,19 @@ static int launch_typed(const ConvArgs& a, hipStream_t stream) {
         if (g_variant >= 20) return launch_zpipe_d<Tag, 6>(a, stream);
 #endif
         if (a.cout % 64 != 0) {
+#ifdef EXASPIM_VARIANTS
             if constexpr (HasPaired<Tag>::value) {
                 if (a.weights_paired && paired_enabled()) {
                     if (a.d % 6 == 0) return launch_zpair_head<Tag, 6>(a, stream);
                     return launch_zpair_head<Tag, 4>(a, stream);
                 }
             }
+#endif
             // 6-plane tiles when the depth divides (96, 48, 24): more dz reuse per LDS read
             if (a.d % 6 == 0) return launch_zpipe_d<Tag, 6>(a, stream);
             return launch_zpipe_d<Tag, 4>(a, stream);
         }
+#ifdef EXASPIM_VARIANTS
         if constexpr (HasPaired<Tag>::value) {
             static int t16 = -1;
             if (t16 < 0) { const char* e = getenv("EXASPIM_T16"); t16 = e && e[0] == '1'; }
@@ -2251,6 +2264,7 @@ static int launch_typed(const ConvArgs& a, hipStream_t stream) {
                 return EXASPIM_OK;
             }
         }
+#endif
 #ifndef EXASPIM_T14_DMA
 #define EXASPIM_T14_DMA 0
 #endif

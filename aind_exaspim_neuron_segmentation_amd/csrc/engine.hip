@@ -41,6 +41,7 @@ struct exaspim_unet {
     int device;
     const char* packed;  // device image (caller-owned)
     LayerTimer* timer = nullptr;
+    uint32_t options = 0;   // EXASPIM_OPT_* (exaspim_unet_set_options)
 };
 
 namespace exaspim {
@@ -106,11 +107,10 @@ static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, in
     // up4.3 skips them, and up4.0 everything its 3x3x3 consumer does not reach.
     const bool trimmed = fuse_head && trim > 0 && 2 * trim < d && 2 * trim < h && 2 * trim < w;
     // conv 2l (inc.3, down1.3, down2.3, down3.3) can write its own max-pool, the input of level l + 1
-    // (EXASPIM_SEPARATE_POOL, read per call: run the stand-alone max-pool launches instead -- the
+    // (EXASPIM_OPT_SEPARATE_POOL, set per handle: run the stand-alone max-pool launches instead -- the
     // tests hold the two to each other bit for bit)
-    const char* sep = getenv("EXASPIM_SEPARATE_POOL");
-    const bool separate_pool = sep && sep[0] == '1';
-    const bool separate_deep = sep && sep[0] == '2';   // measurement aid: only inc.3 keeps its pool
+    const bool separate_pool = (e->options & EXASPIM_OPT_SEPARATE_POOL) != 0;
+    const bool separate_deep = (e->options & EXASPIM_OPT_SEPARATE_DEEP_POOLS) != 0;   // only inc.3 keeps its pool
     bool fuse_pool[4];
     for (int l = 0; l < 4; ++l)
         fuse_pool[l] = !separate_pool && !(separate_deep && l > 0) && conv_can_fuse_pool(p.dtype, p.conv[2 * l].cout, d >> l, h >> l, w >> l);
@@ -423,4 +423,12 @@ extern "C" int exaspim_unet_forward_absmax(exaspim_unet* h, const float* x_dev, 
                   d, hgt, w);
     return forward(h, x_dev, out_dev, n, d, hgt, w, apply_sigmoid, 0, workspace_dev, workspace_bytes,
                    (hipStream_t)stream, nullptr, absmax_dev);
+}
+
+extern "C" int exaspim_unet_set_options(exaspim_unet* h, uint32_t options) {
+    EXA_CHECK_ARG(h != nullptr, "set_options: NULL handle");
+    EXA_CHECK_ARG((options & ~(uint32_t)(EXASPIM_OPT_SEPARATE_POOL | EXASPIM_OPT_SEPARATE_DEEP_POOLS)) == 0,
+                  "set_options: unknown option bits 0x%x", options);
+    h->options = options;
+    return EXASPIM_OK;
 }

@@ -11,6 +11,9 @@
 // consecutive addresses. Max-pool and interpolation act per channel, so they see
 // the tensor as N * C / chunk independent volumes of 32-byte voxel records.
 
+#include <cmath>
+#include <cstdlib>
+
 #include "common.h"
 
 // This file is compiled with -ffp-contract=off (Makefile): the interpolation coordinates
@@ -800,6 +803,174 @@ __global__ __launch_bounds__(256, UPS_MINW) void upsample2_kernel(const uint4* _
     }
 }
 
+// The same interpolation, software-pipelined (r03). In upsample2_kernel a pair of output planes first
+// loads the source plane it is missing and uses it at once, and because vector memory operations retire
+// in order that wait also covers the four stores of the pair before: every pair pays a load round trip
+// plus a store round trip, three waves per SIMD cannot hide it, and the kernel sat at 2.5-2.9 TB/s with
+// its arithmetic-only and store-only halves each at ~175 us. For x2 with align_corners the
+// schedule is regular whenever the first output plane is even (margin even): pair p (outputs 2p, 2p + 1)
+// reads source planes p - 1, p, p + 1 (clamped), i.e. exactly ONE new plane per pair from p = 2 on. So
+// the loop body is branch-free: the new plane's six 16-byte pieces are fetched one pair AHEAD, before the
+// current pair's stores are issued, every store is issued unconditionally (range-checked buffer stores:
+// a row or plane outside the region gets an out-of-range offset / a zero-record descriptor), and hipcc's
+// wait for the prefetched pieces is s_waitcnt vmcnt(4): the four stores stay in flight. Same arithmetic
+// in the same order as upsample2_kernel, bit for bit (test_pipelined_upsampling_equals_the_plain_kernel).
+template <typename T>
+__global__ __launch_bounds__(256, UPS_MINW) void upsample2_pipe_kernel(const uint4* __restrict__ src,
+                                                                uint4* __restrict__ dst, int d, int h,
+                                                                int w, float sz, float sy, float sx,
+                                                                int margin) {
+    constexpr int cg = 2;
+    constexpr int NP = T::kG / 2;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const int od = d * 2, oh = h * 2, ow = w * 2;
+    const int nz = od - 2 * margin, ny = oh - 2 * margin, nx = ow - 2 * margin;
+    const int nzp = (nz + 1) >> 1, nyp = (ny + 1) >> 1;
+    const int nruns = (nzp + kUpsZRun - 1) / kUpsZRun;
+    const unsigned item = blockIdx.y * blockDim.x + threadIdx.x;
+    // (a thread beyond the last item works on the last one and stores nothing)
+    const bool live = item < (unsigned)(nyp * nx * cg);
+    const unsigned it = live ? item : (unsigned)(nyp * nx * cg) - 1u;
+    const int g = it & 1;
+    const int yp = (int)(it >> 1) / nx, x = margin + (int)(it >> 1) - yp * nx;
+    const int nb = blockIdx.x / nruns, run = blockIdx.x - nb * nruns;
+    const int ya = margin + 2 * yp;
+    const bool has_yb = ya + 1 < oh - margin;
+    const LerpPair py = lerp_pair(ya, has_yb, h, sy);
+    int x0, x1;
+    float lx;
+    lerp_coord(x, w, sx, x0, x1, lx);
+    const f2 wx0 = {1.f - lx, 1.f - lx}, wx1 = {lx, lx};
+    // byte offsets of the six pieces inside a source plane (lane constants), plane in the scalar offset
+    const size_t splane = (size_t)h * w * cg * 16;
+    const __amdgpu_buffer_rsrc_t srs = layer_rsrc(reinterpret_cast<const char*>(src) + (size_t)nb * d * splane,
+                                                  (size_t)d * splane);
+    const unsigned pos[3][2] = {{(unsigned)((py.s0 * w + x0) * cg + g) * 16u, (unsigned)((py.s0 * w + x1) * cg + g) * 16u},
+                                {(unsigned)((py.s1 * w + x0) * cg + g) * 16u, (unsigned)((py.s1 * w + x1) * cg + g) * 16u},
+                                {(unsigned)((py.s2 * w + x0) * cg + g) * 16u, (unsigned)((py.s2 * w + x1) * cg + g) * 16u}};
+    const float yA[3] = {py.a0, py.a1, 0.f}, yB[3] = {py.b0, py.b1, py.b2};
+    // output rows of this thread: byte offsets inside an output plane, out of range when not stored
+    const size_t oplane = (size_t)oh * ow * cg * 16;
+    char* const obase = reinterpret_cast<char*>(dst) + (size_t)nb * od * oplane;
+    const unsigned orow[2] = {live ? (unsigned)(((ya + 0) * ow + x) * cg + g) * 16u : 0x80000000u,
+                              live && has_yb ? (unsigned)(((ya + 1) * ow + x) * cg + g) * 16u : 0x80000000u};
+
+    struct Raw { uint4 v[3][2]; };
+    auto fetch = [&](int p) {                      // the six pieces of source plane p (clamped)
+        Raw r;
+        const unsigned so = (unsigned)(p < d - 1 ? p : d - 1) * (unsigned)splane;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const u32x4_b t = __builtin_amdgcn_raw_buffer_load_b128(srs, (int)pos[rr][c], (int)so, 0);
+                r.v[rr][c] = make_uint4(t.x, t.y, t.z, t.w);
+            }
+        return r;
+    };
+    auto interp = [&](const Raw& r, f2 (*q)[NP]) {  // x and y interpolation, as upsample2_kernel's load_plane
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            float v0[T::kG], v1[T::kG];
+            T::unpack(r.v[rr][0], v0);
+            T::unpack(r.v[rr][1], v1);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const f2 xr = __builtin_elementwise_fma(wx1, (f2){v1[2 * j], v1[2 * j + 1]},
+                                                        wx0 * (f2){v0[2 * j], v0[2 * j + 1]});
+                const f2 wa = {yA[rr], yA[rr]}, wb = {yB[rr], yB[rr]};
+                if (rr == 0) {
+                    q[0][j] = wa * xr;
+                    q[1][j] = wb * xr;
+                } else {
+                    if (rr == 1) q[0][j] = __builtin_elementwise_fma(wa, xr, q[0][j]);
+                    q[1][j] = __builtin_elementwise_fma(wb, xr, q[1][j]);
+                }
+            }
+        }
+    };
+    auto emit_pair = [&](int za, const LerpPair& pz, const f2 (*v0)[NP], const f2 (*v1)[NP], const f2 (*v2)[NP]) {
+        const bool has_zb = za + 1 < od - margin;
+#pragma unroll
+        for (int zz = 0; zz < 2; ++zz) {
+            // (zero-record descriptor for a plane that does not exist: a scalar select, no branch)
+            const __amdgpu_buffer_rsrc_t ors = layer_rsrc(obase, zz == 0 || has_zb ? (size_t)od * oplane : (size_t)0);
+#pragma unroll
+            for (int yy = 0; yy < 2; ++yy) {
+                float out[T::kG];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const f2 o = zz == 0
+                        ? __builtin_elementwise_fma((f2){pz.a1, pz.a1}, v1[yy][j], (f2){pz.a0, pz.a0} * v0[yy][j])
+                        : __builtin_elementwise_fma((f2){pz.b2, pz.b2}, v2[yy][j],
+                              __builtin_elementwise_fma((f2){pz.b1, pz.b1}, v1[yy][j], (f2){pz.b0, pz.b0} * v0[yy][j]));
+                    out[2 * j] = o.x; out[2 * j + 1] = o.y;
+                }
+                buf_store16_counted(T::pack(out), ors, orow[yy], (unsigned)(za + zz) * (unsigned)oplane);
+            }
+        }
+    };
+
+    f2 q0[2][NP], q1[2][NP], q2[2][NP];
+    const int pair_end = min(nzp, (run + 1) * kUpsZRun);
+    int pr = run * kUpsZRun;
+    int p = (margin >> 1) + pr;                 // pair index in the un-trimmed output: planes 2p, 2p + 1
+    // ---- prologue: pairs 0 and 1 read planes 0, 1, 2 and do not advance
+    {
+        const int first = p < 2 ? 0 : p - 2;
+        interp(fetch(first), q0);
+        interp(fetch(first + 1), q1);
+        interp(fetch(first + 2), q2);
+        for (; p < 2 && pr < pair_end; ++p, ++pr) {
+            const int za = margin + 2 * pr;
+            const LerpPair pz = lerp_pair(za, za + 1 < od - margin, d, sz);
+            emit_pair(za, pz, q0, q1, q2);
+        }
+    }
+    // ---- steady state: ring = planes (p - 2, p - 1, p) on entry; pair p wants (p - 1, p, p + 1).
+    // "cur" has arrived when an iteration starts: the wait for the pieces fetched in an iteration sits
+    // at its END, behind its four stores, where hipcc can count them (straight-line code: s_waitcnt
+    // vmcnt(4)); at the loop top the entry edge and the back edge would disagree and it would have to
+    // wait for everything. The empty asm is that wait's anchor (it "uses" every fetched register).
+    auto settle = [](Raw& r) {
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                asm volatile("" : "+v"(r.v[rr][c].x), "+v"(r.v[rr][c].y), "+v"(r.v[rr][c].z), "+v"(r.v[rr][c].w));
+    };
+    Raw cur = fetch(p + 1);
+    settle(cur);
+    for (; pr < pair_end; ++pr, ++p) {          // wave-uniform
+        const int za = margin + 2 * pr;
+        const LerpPair pz = lerp_pair(za, za + 1 < od - margin, d, sz);
+#pragma unroll
+        for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+            for (int j = 0; j < NP; ++j) { q0[yy][j] = q1[yy][j]; q1[yy][j] = q2[yy][j]; }
+        Raw nxt = fetch(p + 2);                 // one pair ahead, BEFORE this pair's stores
+        interp(cur, q2);
+        emit_pair(za, pz, q0, q1, q2);
+        settle(nxt);
+        cur = nxt;
+    }
+}
+
+// does pair p of a x2 upsampling of n planes read source planes max(p - 1, 0) .. + 2, in float arithmetic too?
+static bool upsample_schedule_is_regular(int n, float scale) {
+    for (int p = 0; p < n; ++p) {
+        const float s = scale * (float)(2 * p);
+        int i0 = (int)floorf(s);
+        if (i0 > n - 1) i0 = n - 1;
+        if (i0 != (p > 0 ? p - 1 : 0)) return false;
+        const float s1 = scale * (float)(2 * p + 1);
+        int j0 = (int)floorf(s1);
+        if (j0 > n - 1) j0 = n - 1;
+        if (j0 != i0 && j0 != i0 + 1) return false;
+    }
+    return true;
+}
+
 // ---- head: 1x1x1 conv (+ sigmoid), channels-last -> NCDHW float32 -----------
 template <typename T, int OC>
 __global__ __launch_bounds__(256) void head_kernel(const uint4* __restrict__ src,
@@ -961,6 +1132,19 @@ int launch_upsample2(int dtype, const void* src, void* dst, int n, int d, int h,
                   "upsample: grid too large");
     auto scale = [](int in) { return in > 1 ? (float)(in - 1) / (float)(2 * in - 1) : 0.f; };
     dim3 grid((unsigned)planes, (unsigned)((items + 255) / 256));
+    // the software-pipelined kernel when its schedule holds: even first plane, at least three source
+    // planes, one volume per 32-bit descriptor (EXASPIM_PLAIN_UPSAMPLE: the tests hold the two kernels
+    // to each other bit for bit)
+    static const bool plain_only = [] { const char* e = getenv("EXASPIM_PLAIN_UPSAMPLE"); return e && e[0] == '1'; }();
+    const bool pipe = !plain_only && margin % 2 == 0 && d >= 3 && upsample_schedule_is_regular(d, scale(d)) &&
+                      (size_t)8 * d * h * w * 32 < 0x7fffffffULL;
+    if (pipe) {
+        DISPATCH_T(dtype, (upsample2_pipe_kernel<T><<<grid, 256, 0, stream>>>(
+                              static_cast<const uint4*>(src), static_cast<uint4*>(dst), d, h, w,
+                              scale(d), scale(h), scale(w), margin)));
+        EXA_CHECK_HIP(hipGetLastError());
+        return EXASPIM_OK;
+    }
     DISPATCH_T(dtype, (upsample2_kernel<T><<<grid, 256, 0, stream>>>(
                           static_cast<const uint4*>(src), static_cast<uint4*>(dst), d, h, w,
                           scale(d), scale(h), scale(w), margin)));

@@ -128,6 +128,7 @@ bool make_plan(const int32_t channels[5], int32_t out_channels, int32_t dtype,
         woff = align_up(woff + (size_t)27 * (L.ca + L.cb) * L.cout * es, 256);
         L.b_off = woff;
         woff = align_up(woff + (size_t)L.cout * sizeof(float), 256);
+#ifdef EXASPIM_VARIANTS   // (the measured-and-not-adopted kernels' own fragment orders: variant builds only)
         // level-1 layers with 64-cout slices (down1.0, down1.3, up3.0): K = 32 fragments for the
         // 16x16x32 kernel, [pair of chunks][tap 27][16-cout group][lane 64][8 x 16 bit]
         if (dtype != EXASPIM_DT_F32 && L.cout % 64 == 0 && (i == 1 || i == 2 || i == 13)) {
@@ -139,6 +140,7 @@ bool make_plan(const int32_t channels[5], int32_t out_channels, int32_t dtype,
             L.w2_off = woff;
             woff = align_up(woff + (size_t)kPairedFrags * 1024 * ((L.ca + L.cb) / 16) * (L.cout / 32), 256);
         }
+#endif
     }
     p.head_p_off = poff;
     poff += (size_t)out_channels * c[0] + out_channels;

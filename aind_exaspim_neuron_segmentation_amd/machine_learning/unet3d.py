@@ -134,6 +134,7 @@ class UNet3D(nn.Module):
         self._resolved_key = None # parameter state that decision was taken for
         self.auto_report = None   # the measurements behind that decision (resolve_compute_dtype)
         self._workspace = None
+        self.engine_options = 0   # _native.OPT_* bits handed to every engine (bit-identical plans: tests, tools)
 
     # ---- engine management -------------------------------------------------
     def _canonical_params(self):
@@ -182,7 +183,7 @@ class UNet3D(nn.Module):
         key = self._state_key(device, dtype)
         entry = self._engines.get(dtype)
         if entry is not None and key == entry["key"]:
-            return entry["handle"]
+            return self._apply_options(dtype)
         if entry is not None:
             _native.lib().exaspim_unet_destroy(entry["handle"])
             del self._engines[dtype]
@@ -218,8 +219,16 @@ class UNet3D(nn.Module):
             ),
             "exaspim_unet_create",
         )
-        self._engines[dtype] = {"handle": handle, "packed": packed_dev, "key": key}
-        return handle
+        self._engines[dtype] = {"handle": handle, "packed": packed_dev, "key": key, "options": 0}
+        return self._apply_options(dtype)
+
+    def _apply_options(self, dtype):
+        entry = self._engines[dtype]
+        if entry["options"] != self.engine_options:
+            _native.check(_native.lib().exaspim_unet_set_options(entry["handle"], int(self.engine_options)),
+                          "exaspim_unet_set_options")
+            entry["options"] = self.engine_options
+        return entry["handle"]
 
     def _get_workspace(self, n, d, h, w, device, stream):
         """Scratch buffer for one forward; one per HIP stream so that batches in

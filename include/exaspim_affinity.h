@@ -33,7 +33,8 @@ extern "C" {
 #endif
 
 /* 3: exaspim_export_f16 added (entry points are only ever added within a major line);
- * 5: exaspim_unet_forward_absmax, exaspim_histogram_wide (EXASPIM_VOX_F64) */
+ * 5: exaspim_unet_forward_absmax, exaspim_histogram_wide (EXASPIM_VOX_F64),
+ *    exaspim_unet_set_options (replaces an environment switch) */
 #define EXASPIM_ABI_VERSION 5
 
 /* error codes */
@@ -171,6 +172,13 @@ int exaspim_unet_forward_absmax(exaspim_unet* h, const float* x_dev, float* out_
                                 int32_t n, int32_t d, int32_t hgt, int32_t w,
                                 int32_t apply_sigmoid, float* absmax_dev, void* workspace_dev,
                                 size_t workspace_bytes, void* stream);
+
+/* Per-handle switches between bit-identical execution plans (tests and measurements; default 0):
+ * SEPARATE_POOL runs every MaxPool3d(2) (unet3d.py:195) as its own launch instead of in the epilogue
+ * of the convolution in front of it; SEPARATE_DEEP_POOLS does so for all but the first one. */
+#define EXASPIM_OPT_SEPARATE_POOL 1u
+#define EXASPIM_OPT_SEPARATE_DEEP_POOLS 2u
+int exaspim_unet_set_options(exaspim_unet* h, uint32_t options);
 
 /* Measurement hooks (bench.py's roofline leg). timing_begin arms HIP-event
  * timing, on the launch stream, of the MFMA convolutions whose bit is set in

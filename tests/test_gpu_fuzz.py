@@ -89,7 +89,7 @@ def test_predict_geometry_fuzz_vs_oracle(case):
     assert got.shape == want.shape and got.dtype == np.float32
     np.testing.assert_array_equal(got == 0, want == 0)
     err = np.abs(got - want).max() if got.size else 0.0
-    assert err < 1e-5, err
+    assert err < 5e-6, err
     # batches in flight on 1-3 streams: the bits must not depend on it
     res = inference.predict(vol, model, verbose=False, return_device_tensor=True,
                             n_streams=1 + case["seed"] % 3, **kw).cpu().numpy()
@@ -225,7 +225,7 @@ def _net_cases(n, seed):
 def test_network_forward_fuzz(case):
     """Random widths (channel counts from 4 to 768: every cout-slice / tile / split-K choice of
     the launchers), patch shapes, batch sizes, head widths, both up-block variants and the three
-    compute dtypes against the oracle's float32 network: logits within 1e-4 in fp32,
+    compute dtypes against the oracle's float32 network: logits within 5e-5 in fp32,
     probabilities within 1e-3 in fp16 (north_star's bar, the benchmarked mode). bf16 storage
     (8 significant bits; 4e-3 on the full-width network in test_gpu_parity.py) reaches 6.6e-3
     on the narrowest random networks of this hunt: held to 1e-2 here."""
@@ -248,7 +248,7 @@ def test_network_forward_fuzz(case):
     if case["cdt"] == "fp32":
         got = model(x.to(dev)).cpu()
         err = float((got - want).abs().max())
-        assert err < 1e-4, err
+        assert err < 5e-5, err
     else:
         got = model.run(x.to(dev), apply_sigmoid=True).cpu()
         err = float((got - torch.sigmoid(want)).abs().max())

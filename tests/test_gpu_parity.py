@@ -4,7 +4,7 @@ the C ABI, against the CPU oracle on the same seeded inputs and against the
 golden vectors produced by the reference itself.
 
 Tolerances: integer / index / byte work (percentiles, gather, stitch) is
-bit-exact; the fp32 network path is held to 1e-4 abs on logits and 1e-5 abs on
+bit-exact; the fp32 network path is held to 3e-5 abs on logits (measured 3e-6) and 5e-6 abs on
 probabilities (north_star allows 1e-3); the 16-bit mode that bench.py runs
 (fp16 storage, fp32 accumulate) is held to north_star's 1e-3 on the maximum;
 bf16 storage (8 significant bits) is held to 4e-3 (measured 2.3e-3 .. 2.9e-3)
@@ -62,7 +62,7 @@ def test_unet_logits_fp32_vs_oracle(dev, oracle, shape):
     assert got.shape == want.shape
     err = np.abs(got - want).max()
     print(f"fp32 logits {shape}: max|diff| = {err:.3e}")
-    assert err < 1e-4
+    assert err < 3e-5
 
 
 def test_unet_single_96_patch_vs_reference_golden(dev, oracle, golden):
@@ -74,9 +74,9 @@ def test_unet_single_96_patch_vs_reference_golden(dev, oracle, golden):
     err = np.abs(got[:, ::8, ::8, ::8] - g["logits_sub"]).max()
     err2 = np.abs(got[:, 40:44, 17:21, :] - g["logits_slab"]).max()
     print(f"fp32 96^3 logits vs reference: {err:.3e} / {err2:.3e}")
-    assert err < 1e-4 and err2 < 1e-4
+    assert err < 3e-5 and err2 < 3e-5
     sig = torch.sigmoid(logits).cpu().numpy()[0, :, ::8, ::8, ::8]
-    assert np.abs(sig - g["sigmoid_sub"]).max() < 1e-5
+    assert np.abs(sig - g["sigmoid_sub"]).max() < 5e-6
 
 
 @pytest.mark.parametrize("cdt,tol", [("bf16", 4e-3), ("fp16", 1e-3)])
@@ -106,13 +106,13 @@ def test_conv_transpose_variant_vs_reference_golden_and_oracle(dev, oracle, gold
                 np.abs(got[1, :, 17, 9, :] - g["logits_row"]).max())
     e_orc = np.abs(got - want).max()
     print(f"convT fp32 logits: vs reference {e_ref:.3e}, vs oracle {e_orc:.3e}")
-    assert e_ref < 1e-4 and e_orc < 1e-4
+    assert e_ref < 3e-5 and e_orc < 3e-5
     vol = synthetic.synth_volume((56, 40, 48), seed=61)
     pred = inference.predict(vol, model, batch_size=3, patch_shape=(32, 32, 32),
                              overlap=(8, 8, 8), trim=4, verbose=False)
     e_pred = np.abs(pred[:, ::2, ::2, ::2] - g["pred_sub"]).max()
     print(f"convT fp32 predict vs reference: {e_pred:.3e}")
-    assert e_pred < 1e-5
+    assert e_pred < 5e-6
 
 
 @pytest.mark.parametrize("cdt,tol", [("bf16", 4e-3), ("fp16", 1e-3)])
@@ -137,7 +137,7 @@ def test_conv_transpose_half_width(dev, oracle):
     x = normalized_input(oracle, (16, 32, 16), seed=63, n=2)
     want = oracle.unet_forward(x, oracle.OracleModel(sd).sd).numpy()
     got = model(x.to(dev)).cpu().numpy()
-    assert np.abs(got - want).max() < 1e-4
+    assert np.abs(got - want).max() < 5e-5
 
 
 @pytest.mark.parametrize("cdt", ["fp32", "bf16"])
@@ -179,7 +179,7 @@ def test_fused_pool_matches_oracle_stages(dev, oracle, golden):
         x = normalized_input(oracle, shape, seed=73, n=n)
         want = oracle.unet_forward(x, oracle.OracleModel(sd).sd).numpy()
         got = model(x.to(dev)).cpu().numpy()
-        assert np.abs(got - want).max() < 1e-4
+        assert np.abs(got - want).max() < 5e-5
 
 
 @pytest.mark.parametrize("wm,shape,n", [(3, (16, 16, 32), 1), (0.25, (32, 16, 16), 2), (1, (16, 16, 16), 33)])
@@ -249,7 +249,7 @@ def test_validation_tiling_loop(dev, oracle, golden):
     want = oracle.unet_forward(torch.from_numpy(tiles), oracle.OracleModel(sd).sd).numpy()
     err = np.abs(got - want).max()
     print(f"validation tiling loop, {len(tiles)} tiles of {ps}: max|diff| = {err:.3e}")
-    assert err < 1e-4
+    assert err < 5e-5
 
 
 def test_unet_rejects_bad_inputs(dev):
@@ -272,7 +272,7 @@ def test_engine_repacks_after_load_state_dict(dev, oracle):
     b = model(x).cpu().numpy()
     want = oracle.unet_forward(x.cpu(), oracle.OracleModel(sd2).sd).numpy()
     assert np.abs(a - b).max() > 1e-3
-    assert np.abs(b - want).max() < 1e-4
+    assert np.abs(b - want).max() < 5e-5
 
 
 # ---------------------------------------------------------- pre-processing ---
@@ -387,14 +387,14 @@ def test_predict_fp32_vs_reference_golden_and_oracle(dev, oracle, golden):
     want = oracle.predict(vol, oracle.OracleModel(sd), **kw)
     err = np.abs(got - want).max()
     print(f"predict fp32: vs reference golden {err_ref:.3e}, vs oracle {err:.3e}")
-    assert err_ref < 1e-5 and err < 1e-5
+    assert err_ref < 5e-6 and err < 5e-6
     np.testing.assert_array_equal(got == 0, want == 0)  # uncovered border stays exactly 0
 
     model1, sd1 = make_model(dev, out_channels=1, seed=4)
     kw1 = dict(batch_size=5, patch_shape=(32, 32, 32), overlap=(16, 16, 16), trim=2)
     got1 = inference.predict(vol, model1, affinity_mode=False, verbose=False, **kw1)
     assert got1.shape == (72, 40, 56)
-    assert np.abs(got1[::2, ::2, ::2] - g["pred_fg"]).max() < 1e-5
+    assert np.abs(got1[::2, ::2, ::2] - g["pred_fg"]).max() < 5e-6
 
 
 def test_predict_default_config_160_vs_reference_golden(dev, golden):
@@ -406,8 +406,8 @@ def test_predict_default_config_160_vs_reference_golden(dev, golden):
     got = inference.predict(vol, model, batch_size=8, verbose=False)
     err = np.abs(got[:, ::5, ::5, ::5] - g["pred_sub"]).max()
     print(f"predict 160^3 defaults vs reference: {err:.3e}")
-    assert err < 1e-5
-    assert np.abs(got[:, 80, 81, :] - g["pred_line"]).max() < 1e-5
+    assert err < 5e-6
+    assert np.abs(got[:, 80, 81, :] - g["pred_line"]).max() < 5e-6
     zero = (got == 0).all(axis=0)
     assert abs(zero.mean() - float(g["zero_fraction"])) < 1e-12
     np.testing.assert_array_equal(zero.all(axis=(1, 2)), g["zero_z"])
@@ -426,7 +426,7 @@ def test_predict_input_variants(dev, oracle):
     volf = (vol.astype(np.float32) * 0.5)[None, None]
     want = oracle.predict(volf, oracle.OracleModel(sd), **kw)
     got = inference.predict(volf, model, verbose=False, **kw)
-    assert np.abs(got - want).max() < 1e-5
+    assert np.abs(got - want).max() < 5e-6
     # volume smaller than the overlap on one axis -> no patches -> zeros
     tiny = synthetic.synth_volume((8, 48, 40), seed=1)
     out = inference.predict(tiny, model, verbose=False, **kw)
@@ -499,7 +499,7 @@ def test_full_size_512_periodic_property_and_oracle(dev, oracle):
     ref = np.ix_(np.arange(3), src[::7], src[::5], src)
     err = np.abs(got[sub] - want[ref]).max()
     print(f"512^3 periodic vs oracle(224^3): max|diff| = {err:.3e}")
-    assert err < 1e-5
+    assert err < 5e-6
 
 
 def test_full_size_1024_bf16_periodic_property(dev):
@@ -540,7 +540,7 @@ def test_half_width_model_channel_padding(dev, oracle):
     x = normalized_input(oracle, (32, 32, 48), seed=50, n=2)
     want = oracle.unet_forward(x, oracle.OracleModel(sd).sd).numpy()
     got = model(x.to(dev)).cpu().numpy()
-    assert np.abs(got - want).max() < 1e-4
+    assert np.abs(got - want).max() < 5e-5
 
 
 @pytest.mark.parametrize("cdt,tol", [("fp16", 1e-3), ("bf16", 4e-3)])
@@ -575,7 +575,7 @@ def test_predict_voxel_dtypes_vs_oracle(dev, oracle, name, clip):
     got = inference.predict(vol, model, verbose=False, **kw)
     err = np.abs(got - want).max()
     print(f"predict {name}: max|diff| = {err:.3e}")
-    assert err < 1e-5
+    assert err < 5e-6
     np.testing.assert_array_equal(got == 0, want == 0)
 
 
@@ -609,7 +609,7 @@ def test_predict_takes_the_dtypes_the_reference_takes(dev, oracle, name, clip):
     got = inference.predict(vol, model, verbose=False, **kw)
     err = np.abs(got - want).max()
     print(f"predict {name}: max|diff| = {err:.3e}")
-    assert err < 1e-5
+    assert err < 5e-6
     np.testing.assert_array_equal(got == 0, want == 0)
     # percentiles are numpy's, bit for bit
     dv = inference.DeviceVolume.from_array(vol, dev)
@@ -654,7 +654,7 @@ def test_predict_takes_what_float32_cannot_carry(dev, oracle, name, clip):
         want = oracle.predict(vol, oracle.OracleModel(sd), **dict(kw, brightness_clip=1e300))
     err = np.abs(got - want).max()
     print(f"predict {name}, clip {clip}: max|diff| = {err:.3e}")
-    assert err < 1e-5
+    assert err < 5e-6
     np.testing.assert_array_equal(got == 0, want == 0)
     # the device-resident route and a chunked source (no knowledge of the values: float64 carrier)
     t = inference.predict(vol, model, verbose=False, return_device_tensor=True, **kw)
@@ -683,12 +683,20 @@ def test_opt_in_kernel_variants_match_the_reference(dev, golden, switch):
     """EXASPIM_ZPAIR=1 runs the 32-cout-slice layers on conv3x3x3_zpair (v_mfma_f32_16x16x32,
     pairs of taps per instruction, paired weight fragments of plan.cpp); EXASPIM_T16=1 runs the
     64-cout layers of level 1 on conv3x3x3_t16 (v_mfma_f32_16x16x32 over pairs of channel
-    chunks, persistent workgroups, LDS-DMA, K = 32 weight fragments). The switches are read once
-    per process, so the check runs in a child process -- default-config 160^3 predict in fp16
-    against the reference's golden output, same 1e-3 bar."""
+    chunks, persistent workgroups, LDS-DMA, K = 32 weight fragments). Both were measured and not
+    adopted and exist only in a -DEXASPIM_VARIANTS build of the library
+    (make -C .../csrc variant NAME=variants VFLAGS=-DEXASPIM_VARIANTS), which a child process loads
+    through EXASPIM_LIB -- default-config 160^3 predict in fp16 against the reference's golden
+    output, same 1e-3 bar. Skipped when that build is not there."""
     import os
     import subprocess
     import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    variants = os.path.join(root, "aind_exaspim_neuron_segmentation_amd", "csrc", "build", "variants",
+                            "lib_variants.so")
+    if not os.path.exists(variants):
+        pytest.skip("no -DEXASPIM_VARIANTS build of the library")
 
     code = """
 import numpy as np, torch, sys
@@ -707,7 +715,7 @@ print("variant fp16 max %%.3e mean %%.3e" %% (err.max(), err.mean()))
 assert err.max() < 1e-3
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
        os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g6_default_160.npz"))
-    env = dict(os.environ, **{switch: "1"})
+    env = dict(os.environ, **{switch: "1", "EXASPIM_LIB": variants})
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     print(out.stdout[-400:], out.stderr[-400:])
     assert out.returncode == 0
@@ -716,11 +724,11 @@ assert err.max() < 1e-3
 @pytest.mark.parametrize("dtype", ["fp16", "bf16", "fp32"])
 @pytest.mark.parametrize("wm,shape,n", [(1, (96, 96, 96), 2), (1, (48, 64, 80), 3), (0.5, (32, 48, 64), 2),
                                         (2, (16, 32, 48), 1), (0.25, (96, 32, 16), 5)])
-def test_fused_max_pool_equals_the_separate_launch(dev, oracle, dtype, wm, shape, n, monkeypatch):
+def test_fused_max_pool_equals_the_separate_launch(dev, oracle, dtype, wm, shape, n):
     """The last convolution of every encoder level writes the level's MaxPool3d(2)
     (unet3d.py:194-196) from its epilogue (z-column kernel: wave-local; t14 kernel: the
-    tile's output groups parked in LDS, 16-bit modes). EXASPIM_SEPARATE_POOL=1 (read per
-    call) runs the stand-alone max-pool launches instead: the logits must be the same bits
+    tile's output groups parked in LDS, 16-bit modes). The engine option EXASPIM_OPT_SEPARATE_POOL
+    (exaspim_unet_set_options) runs the stand-alone max-pool launches instead: the logits must be the same bits
     -- a maximum of stored values either way -- over the tile shapes of all pyramid levels
     (96/48/24/12, 80/40/20/10, 64/32/16/8 ... wide), widths and dtypes."""
     from aind_exaspim_neuron_segmentation_amd.machine_learning.unet3d import UNet3D
@@ -730,10 +738,13 @@ def test_fused_max_pool_equals_the_separate_launch(dev, oracle, dtype, wm, shape
     model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
     model = model.to(dev).eval()
     x = normalized_input(oracle, shape, seed=31, n=n).to(dev)
+    from aind_exaspim_neuron_segmentation_amd import _native
+
     fused = model(x).cpu().numpy()
-    monkeypatch.setenv("EXASPIM_SEPARATE_POOL", "1")
+    model.engine_options = _native.OPT_SEPARATE_POOL
     separate = model(x).cpu().numpy()
-    monkeypatch.delenv("EXASPIM_SEPARATE_POOL")
+    model.engine_options = 0
+    assert np.array_equal(model(x).cpu().numpy(), fused)
     assert np.isfinite(fused).all()
     assert np.array_equal(fused, separate)
 
