@@ -1045,10 +1045,10 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
         // (the empty asm makes every staged register "used", so hipcc puts the s_waitcnt for the
         // prefetch loads in front of it; afterwards they are plain values). Left to the staging behind
         // the epilogue, that wait is s_waitcnt vmcnt(0) and also covers the epilogue's stores -- a tile
-        // boundary then costs a full store round trip. A counted wait (vmcnt(#stores)) behind
-        // unconditional range-checked stores is NOT an alternative: a store the range check drops
-        // retires early, out of order with the older loads, and the count lets stale staging registers
-        // through (measured: trimmed forward no longer repeatable).
+        // boundary then costs a full store round trip. (A counted wait, vmcnt(#stores), behind
+        // unconditional range-checked stores would do as well -- range-dropped stores retire in order
+        // with older loads, tools/vmcnt_order.hip -- but the epilogue's stores go through buf_store16,
+        // whose inline assembly hipcc cannot count.)
         if (EXASPIM_SETTLE_FIRST && has_next) {
 #pragma unroll
             for (int i = 0; i < NITEMS + WITEMS; ++i)
@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
             // Every store is ISSUED, as a range-checked buffer store: a lane outside the region gets
             // an out-of-range offset and a plane outside it the zero-record descriptor, and the
             // hardware drops the write -- no branch, no per-store address arithmetic on the vector ALU.
-            // (Nothing may COUNT on these stores, see EXASPIM_SETTLE_FIRST above.)
+            // (buf_store16: hazard-safe and invisible to hipcc's wait counts, see common.h.)
             const unsigned ovoff = okyx ? (unsigned)(gy * a.w + gx) * 32u + half_e * 16u : kOutOfRange;
 #else
             char* const dvox = dplane + ((size_t)gy * a.w + gx) * 32 + half_e * 16;

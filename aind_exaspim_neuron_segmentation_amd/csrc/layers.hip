@@ -1120,7 +1120,7 @@ int launch_maxpool2(int dtype, const void* src, void* dst, int n, int d, int h, 
 }
 
 int launch_upsample2(int dtype, const void* src, void* dst, int n, int d, int h, int w,
-                     int c, int margin, hipStream_t stream) {
+                     int c, int margin, hipStream_t stream, bool plain_kernel) {
     if (margin < 0 || margin >= d || margin >= h || margin >= w) margin = 0;
     const int nv = n * (c * dtype_size(dtype) / 32);   // chunk planes = independent volumes
     // items of one pair of output planes: (row pair, column, 16-byte group)
@@ -1133,10 +1133,9 @@ int launch_upsample2(int dtype, const void* src, void* dst, int n, int d, int h,
     auto scale = [](int in) { return in > 1 ? (float)(in - 1) / (float)(2 * in - 1) : 0.f; };
     dim3 grid((unsigned)planes, (unsigned)((items + 255) / 256));
     // the software-pipelined kernel when its schedule holds: even first plane, at least three source
-    // planes, one volume per 32-bit descriptor (EXASPIM_PLAIN_UPSAMPLE: the tests hold the two kernels
-    // to each other bit for bit)
-    static const bool plain_only = [] { const char* e = getenv("EXASPIM_PLAIN_UPSAMPLE"); return e && e[0] == '1'; }();
-    const bool pipe = !plain_only && margin % 2 == 0 && d >= 3 && upsample_schedule_is_regular(d, scale(d)) &&
+    // planes, one volume per 32-bit descriptor ("plain_kernel", EXASPIM_OPT_PLAIN_UPSAMPLE: the tests
+    // hold the two kernels to each other bit for bit)
+    const bool pipe = !plain_kernel && margin % 2 == 0 && d >= 3 && upsample_schedule_is_regular(d, scale(d)) &&
                       (size_t)8 * d * h * w * 32 < 0x7fffffffULL;
     if (pipe) {
         DISPATCH_T(dtype, (upsample2_pipe_kernel<T><<<grid, 256, 0, stream>>>(

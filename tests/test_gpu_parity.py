@@ -749,6 +749,35 @@ def test_fused_max_pool_equals_the_separate_launch(dev, oracle, dtype, wm, shape
     assert np.array_equal(fused, separate)
 
 
+@pytest.mark.parametrize("dtype", ["fp16", "bf16", "fp32"])
+@pytest.mark.parametrize("wm,shape,n,trim", [(1, (96, 96, 96), 2, 8), (1, (96, 96, 96), 1, 0), (1, (48, 64, 80), 3, 4),
+                                             (0.5, (32, 48, 64), 2, 6), (2, (16, 32, 48), 1, 2), (1, (96, 96, 96), 1, 7),
+                                             (0.25, (96, 32, 16), 5, 0)])
+def test_pipelined_upsampling_equals_the_plain_kernel(dev, oracle, dtype, wm, shape, n, trim):
+    """nn.Upsample(x2, trilinear, align_corners=True) (unet3d.py:248-250) runs on a software-pipelined
+    kernel whenever the first output plane it has to produce is even (every level of the full forward; the
+    trimmed forward's level 0 with an even margin trim - 2): one new source plane per pair of output planes,
+    fetched a pair ahead, branch-free range-checked stores. The engine option EXASPIM_OPT_PLAIN_UPSAMPLE
+    runs the plain kernel instead: same arithmetic in the same order, so the same bits -- over the pyramid
+    levels of several patch shapes (96/48/24/12, 80/40/20/10 ... wide; source depths down to 1 plane, where
+    the plain kernel is the only one), widths, dtypes, and odd trims (plain kernel either way)."""
+    from aind_exaspim_neuron_segmentation_amd import _native
+    from aind_exaspim_neuron_segmentation_amd.machine_learning.unet3d import UNet3D
+
+    sd = synthetic.synth_state_dict(3, wm, seed=29)
+    model = UNet3D(output_channels=3, width_multiplier=wm, compute_dtype=dtype)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    model = model.to(dev).eval()
+    x = normalized_input(oracle, shape, seed=37, n=n).to(dev)
+    inner = (Ellipsis,) + ((slice(trim, -trim),) * 3 if trim else (slice(None),) * 3)
+    piped = model.run(x, apply_sigmoid=True, trim=trim)[inner].cpu().numpy()
+    model.engine_options = _native.OPT_PLAIN_UPSAMPLE
+    plain = model.run(x, apply_sigmoid=True, trim=trim)[inner].cpu().numpy()
+    model.engine_options = 0
+    assert np.isfinite(piped).all()
+    assert np.array_equal(piped, plain)
+
+
 def _split_words(x, kind):
     """hi | lo << 16 of float32 values, hi = half(x), lo = half(x - float(hi)) (numpy)."""
     if kind == "f16":

@@ -48,6 +48,7 @@ int main(int argc, char** argv) {
         printf("%-44s %8.1f us   %6.2f TB/s (algorithmic bytes)\n", name, ms / reps * 1e3, bytes / (ms / reps * 1e-3) * 1e-12);
     };
     using namespace exaspim;
+    const bool plain = getenv("EXASPIM_PLAIN_UPSAMPLE") != nullptr;   // (tool only: the un-pipelined upsampling kernel)
     if (argc > 1) {   // check: an output voxel must not depend on the margin (role inside its pair)
         const int c = 8, e = 8, oe = 16;                       // one fp32 chunk plane, 8^3 -> 16^3
         std::vector<float> hs((size_t)e * e * e * c), o0((size_t)oe * oe * oe * c), o1(o0.size());
@@ -122,15 +123,15 @@ int main(int argc, char** argv) {
     }
     // up4.up: 32 ch, 48^3 -> 96^3, margin 6 (trimmed forward) and 0
     time("upsample 32ch 48->96 margin 6", 16.0 * 64 * (84.0 * 84 * 84 + 48 * 48 * 48),
-         [&] { launch_upsample2(dt, a, b, n, 48, 48, 48, 32, 6, 0); });
+         [&] { launch_upsample2(dt, a, b, n, 48, 48, 48, 32, 6, 0, plain); });
     time("upsample 32ch 48->96 margin 0", 16.0 * 64 * (96.0 * 96 * 96 + 48 * 48 * 48),
-         [&] { launch_upsample2(dt, a, b, n, 48, 48, 48, 32, 0, 0); });
+         [&] { launch_upsample2(dt, a, b, n, 48, 48, 48, 32, 0, 0, plain); });
     time("upsample 64ch 24->48", 16.0 * 128 * (48.0 * 48 * 48 + 24 * 24 * 24),
-         [&] { launch_upsample2(dt, a, b, n, 24, 24, 24, 64, 0, 0); });
+         [&] { launch_upsample2(dt, a, b, n, 24, 24, 24, 64, 0, 0, plain); });
     time("upsample 128ch 12->24", 16.0 * 256 * (24.0 * 24 * 24 + 12 * 12 * 12),
-         [&] { launch_upsample2(dt, a, b, n, 12, 12, 12, 128, 0, 0); });
+         [&] { launch_upsample2(dt, a, b, n, 12, 12, 12, 128, 0, 0, plain); });
     time("upsample 256ch 6->12", 16.0 * 512 * (12.0 * 12 * 12 + 6 * 6 * 6),
-         [&] { launch_upsample2(dt, a, b, n, 6, 6, 6, 256, 0, 0); });
+         [&] { launch_upsample2(dt, a, b, n, 6, 6, 6, 256, 0, 0, plain); });
     time("maxpool 64ch 48->24", 16.0 * 128 * (48.0 * 48 * 48 + 24 * 24 * 24),
          [&] { launch_maxpool2(dt, a, b, n, 48, 48, 48, 64, 0); });
     time("inc.0 (pad + conv_first16) 96^3 -> 32ch", 16.0 * 96 * 96 * 96 * (4 + 64),
