@@ -455,7 +455,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
                 const unsigned dst = __builtin_amdgcn_readfirstlane(
                     lds_base + (unsigned)((buf * IMG + (j / NBLK) * HV + (j % NBLK) * 64) * 16));
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                             :: "s"(dst), "v"(dvoff[k]), "s"(rsrc), "s"(cbase) : "memory");   // m0 is not allocatable: nothing of the compiler's lives in it
+                             :: "s"(dst), "v"(dvoff[k]), "s"(rsrc), "s"(cbase) : "memory", "m0");   // m0 is not allocatable: nothing of the compiler's lives in it
             }
         }
     };
@@ -1032,6 +1032,11 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (ES == 2 && EXASPIM_SETPRIO) __builtin_amdgcn_s_setprio(0);
+            // The 16-bit MFMAs above are inline assembly (mma_inplace), so hipcc's hazard recognizer does
+            // not know that the accumulators were written by the matrix pipe: the wait states between an
+            // 8-pass MFMA and the first vector-ALU read of its destination (the epilogue) are spelled out
+            // here instead of being left to whatever happens to stand in between.
+            if (ES == 2) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 1");
             if (c < 4) EXA_TRACE(3 + 3 * c);
             __syncthreads();   // every wave is done reading this chunk's image
             if (c < 4) EXA_TRACE(4 + 3 * c);
@@ -1886,7 +1891,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3x3_t16(ConvArgs a, int tiles_z,
                     lds_base + (unsigned)((buf * IMG + pl * HV + (j % NBLK) * 64) * 16));
                 const unsigned soff = cbase + (unsigned)(pl >> 1) * (unsigned)patch_vox * 32u;
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                             :: "s"(dst), "v"(dvoff[k]), "s"(rsrc), "s"(soff) : "memory");   // m0 is not allocatable: nothing of the compiler's lives in it
+                             :: "s"(dst), "v"(dvoff[k]), "s"(rsrc), "s"(soff) : "memory", "m0");   // m0 is not allocatable: nothing of the compiler's lives in it
             }
         }
     };

@@ -1,5 +1,7 @@
+"""Four identical forward passes (full and trimmed, fp16 and fp32) must agree bit for bit: run on the MI355X box
+after touching a kernel's stores or waits (it caught the gfx950 store-data hazard, profiles/r03_gfx950_hazards.txt)."""
 import sys, os, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from aind_exaspim_neuron_segmentation_amd.machine_learning.unet3d import UNet3D
 from aind_exaspim_neuron_segmentation_amd.utils import synthetic
 dev = torch.device("cuda:0")
