@@ -300,8 +300,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
     // on complementary banks for every ds_read_b128 lane group (PMC: bank-conflict
     // cycles 50 % -> 17 % of the LDS-active cycles, which drop by 39 %; the launch time
     // does not move, LDS is not what limits this kernel). Padding is never touched.
+    // (12-wide rows: a ds_read_b128 lane group of 16 voxels always wraps a 12-voxel row, and with the dense
+    // row stride of 14 slots the two pieces share bank slots -- the counters show 50 % conflict cycles at
+    // the 12^3 level. A row stride of 28 slots (= 12 mod 16, conflict-free for all 27 taps by enumeration,
+    // channel groups 8 slots apart mod 16 for the staging writes) was measured in round 3 and, like round
+    // 2's attempt, is SLOWER: down3.0 58 -> 66 us, down3.3 107 -> 127, up1.0 204 -> 243 per batch -- twice
+    // the LDS image and a wider staging scatter cost more than the conflicts. Dense rows stay.)
     constexpr int HXS = TX == 24 ? 40 : HX;
-    constexpr int HVR = HZ * HY * HXS;              // slots of a channel-group plane that hold voxels
+    constexpr int PLS = HY * HXS;                   // plane stride
+    constexpr int HVR = HZ * PLS;                   // slots of a channel-group plane that hold voxels
     // plane stride: with DMA a plane is written in whole 64-slot blocks (the tail lanes write zeros)
     constexpr int HV = DMA ? (HVR + 63) / 64 * 64 : HVR;
     constexpr int HVD = HZ * HY * HX;               // halo voxels (staging enumerates these)
@@ -356,7 +363,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
         int m = (wm * MT + mt) * 32 + r;
         m = m < TILE_VOX ? m : TILE_VOX - 1;
         const int z = m / (TY * TX), y = (m / TX) % TY, x = m % TX;
-        base[mt] = (z * HY + y) * HXS + x + half * HV;
+        base[mt] = z * PLS + y * HXS + x + half * HV;
     }
 
     // staging piece i = tid + it * NTHREADS is 16-byte group i & 1 of halo voxel
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
         for (int it = 0; it < NITEMS; ++it) {
             const int i = tid + it * NTHREADS;
             const int hv = i >> 1;
-            if (i < 2 * HVD) lds[(i & 1) * HV + (hv / HX) * HXS + hv % HX] = stg[it];
+            if (i < 2 * HVD) lds[(i & 1) * HV + (hv / (HY * HX)) * PLS + ((hv / HX) % HY) * HXS + hv % HX] = stg[it];
         }
     };
 
@@ -498,7 +505,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
         uint4 xf[2][MT];
         {
             constexpr int t0 = tap_of(0);
-            constexpr int tapoff0 = ((t0 / 9) * HY + (t0 / 3) % 3) * HXS + t0 % 3;
+            constexpr int tapoff0 = (t0 / 9) * PLS + ((t0 / 3) % 3) * HXS + t0 % 3;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) xf[0][mt] = img[base[mt] + tapoff0];
         }
@@ -521,7 +528,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MINW) void conv3x3x3_t14(
 #endif
             if (t + 1 < 27) {
                 const int tn = tap_of(t + 1);
-                const int tapoff = ((tn / 9) * HY + (tn / 3) % 3) * HXS + tn % 3;
+                const int tapoff = (tn / 9) * PLS + ((tn / 3) % 3) * HXS + tn % 3;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) xf[(t + 1) & 1][mt] = img[base[mt] + tapoff];
             }
