@@ -219,9 +219,10 @@ bool conv_can_fuse_head(int cout, int w, int head_oc);
 bool conv_can_fuse_pool(int dtype, int cout, int d, int h, int w);
 
 // xpad: scratch for the zero-bordered copy of x, n * (d+2)(h+2)(wd+2) floats
+// first_no_strips: keep the per-group kernel (the tests hold it to the row-strip kernel bit for bit)
 int launch_conv_first(int dtype, const float* x, float* xpad, const float* w, const float* bias,
                       void* dst, int n, int d, int h, int wd, int c0p, float slope,
-                      hipStream_t stream);
+                      hipStream_t stream, bool first_no_strips = false);
 // ConvTranspose3d(k=2, s=2): (n, d, h, w, cin) -> (n, 2d, 2h, 2w, cout), bias, no activation
 int launch_convt2(int dtype, const void* src, const void* weights, const float* bias, void* dst,
                   int n, int d, int h, int w, int cin, int cout, hipStream_t stream);

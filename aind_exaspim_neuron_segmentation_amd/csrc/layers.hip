@@ -600,6 +600,171 @@ __global__ __launch_bounds__(256) void conv_first16_kernel(
     }
 }
 
+// inc.0 on row strips (r03): a workgroup of four waves owns 4 rows x the whole width of one plane of a
+// patch and keeps the 3 planes x 6 rows x (width + 2) input words its 27 taps touch in LDS. The ablations
+// of conv_first16_kernel say its 16 tap loads per 32-voxel group and its stores each
+// take their own time and do not overlap; here a thread issues 7 global loads per STRIP (12 groups at a
+// width of 96) instead of 48, for the next strip and before the current strip's stores, the taps are
+// ds_read_b32 (consecutive lanes, consecutive words: no conflicts), and the only wait for global data sits
+// behind the strip's stores, which hipcc counts (s_waitcnt vmcnt(#stores)). Same operands to the same six
+// MFMAs per group as conv_first16_kernel: same bits.
+constexpr int kStripRows = 4;
+template <typename T>
+__global__ __launch_bounds__(256) void conv_first16_strip_kernel(
+    const unsigned* __restrict__ xp, const float* __restrict__ w, const float* __restrict__ bias,
+    void* __restrict__ dst, int n, int d, int h, int wd, int c0p, float slope) {
+    constexpr int G = T::kG;
+    constexpr int ES = 16 / G;
+    constexpr int RECB = 32 * ES;
+    constexpr int RECP = RECB + 16;
+    constexpr int CPT = RECB / 32;
+    constexpr int R = kStripRows;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, r = lane & 31;
+    const int co_tile = blockIdx.y * 32;
+    const int hw = h * wd, dhw = d * hw;
+    const int pw = wd + 2, phw = (h + 2) * pw;    // padded row / plane strides (global)
+    const int trow = pw, tplane = (R + 2) * pw;   // row / plane strides of the LDS tile
+    const int twords = 3 * tplane;                // words of one input tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned* const tile0 = reinterpret_cast<unsigned*>(smem);
+    char* const tr = smem + 2 * ((twords * 4 + 15) / 16 * 16);
+    char* const wl = tr + wave * (32 * RECP);
+
+    // A operands and the taps' offsets inside the LDS tile (words)
+    uint4 whi[2], wlo[2];
+    int rel[2][8];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        float wv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = 8 * (half + 2 * st) + j;
+            const bool real = t < 27;
+            const int tt = real ? t : 0;
+            wv[j] = real ? w[tt * c0p + co_tile + r] : 0.f;
+            rel[st][j] = (tt / 9) * tplane + ((tt / 3) % 3) * trow + tt % 3 + r;
+        }
+        split8<T>(wv, whi[st], wlo[st]);
+    }
+    float4 bq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        bq[q] = *reinterpret_cast<const float4*>(bias + co_tile + 8 * q + 4 * half);
+
+    // this thread's words of a tile: word i = tid + k * 256 -> (plane, row, x) of the tile
+    constexpr int NLOAD = 8;                       // ceil(3 * 6 * (128 + 2) / 256) covers widths up to 128
+    unsigned goff[NLOAD];                          // byte offset inside the padded patch relative to the strip origin
+#pragma unroll
+    for (int k = 0; k < NLOAD; ++k) {
+        const int i = threadIdx.x + k * 256;
+        const int pl = i / tplane, rem = i - pl * tplane;
+        const int ry = rem / trow, x = rem - ry * trow;
+        goff[k] = i < twords ? (unsigned)((pl * phw + ry * pw + x) * 4) : 0x80000000u;
+    }
+    const size_t xpatch_bytes = (size_t)(d + 2) * phw * 4;
+    const size_t opatch_bytes = (size_t)(c0p * ES / 32) * dhw * 32;
+    const int strips_y = h / R;
+    const int nstrips = n * d * strips_y;
+    const int gpr = wd / 32;                       // groups per row
+    const int ngroups = R * gpr;                   // groups per strip
+
+    struct Strip { int nb, z, y0; };
+    auto locate = [&](int sidx) {
+        Strip t;
+        const int si = __builtin_amdgcn_readfirstlane(sidx);
+        t.nb = si / (d * strips_y);
+        const int rem = si - t.nb * (d * strips_y);
+        t.z = rem / strips_y;
+        t.y0 = (rem - t.z * strips_y) * R;
+        return t;
+    };
+    unsigned stage[NLOAD];
+    auto fetch = [&](const Strip& t) {             // padded coordinates: tap (0,0,0) of voxel (z, y0, 0) is (z, y0, 0)
+        const __amdgpu_buffer_rsrc_t rs =
+            layer_rsrc(reinterpret_cast<const char*>(xp) + (size_t)t.nb * xpatch_bytes, xpatch_bytes);
+        const unsigned so = (unsigned)((t.z * phw + t.y0 * pw) * 4);
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) stage[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)goff[k], (int)so, 0);
+    };
+    auto park = [&](unsigned* tile) {
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) {
+            const int i = threadIdx.x + k * 256;
+            if (i < twords) tile[i] = stage[k];
+        }
+    };
+
+    int sidx = blockIdx.x;
+    if (sidx >= nstrips) return;
+    Strip cur = locate(sidx);
+    fetch(cur);
+    park(tile0);
+    __syncthreads();
+    const int vv = lane >> 1, sub = lane & 1;
+    int buf = 0;
+    for (;;) {
+        const int snext = sidx + gridDim.x;
+        const bool more = snext < nstrips;
+        const Strip nxt = locate(more ? snext : sidx);
+        fetch(nxt);                                // next strip's words, BEFORE this strip's stores
+        const unsigned* const tile = tile0 + buf * ((twords + 3) / 4 * 4);
+        const __amdgpu_buffer_rsrc_t ors =
+            layer_rsrc(static_cast<char*>(dst) + (size_t)cur.nb * opatch_bytes, opatch_bytes);
+        for (int q = wave; q < ngroups; q += 4) {  // wave-uniform
+            const int ry = q / gpr, xs = (q - ry * gpr) * 32;
+            const int base = ry * trow + xs;
+            f32x16_ct acc;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                acc[4 * qq + 0] = bq[qq].x; acc[4 * qq + 1] = bq[qq].y;
+                acc[4 * qq + 2] = bq[qq].z; acc[4 * qq + 3] = bq[qq].w;
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                unsigned x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = tile[base + rel[st][j]];
+                uint4 xhi, xlo;
+                xhi.x = __builtin_amdgcn_perm(x[1], x[0], 0x05040100u); xlo.x = __builtin_amdgcn_perm(x[1], x[0], 0x07060302u);
+                xhi.y = __builtin_amdgcn_perm(x[3], x[2], 0x05040100u); xlo.y = __builtin_amdgcn_perm(x[3], x[2], 0x07060302u);
+                xhi.z = __builtin_amdgcn_perm(x[5], x[4], 0x05040100u); xlo.z = __builtin_amdgcn_perm(x[5], x[4], 0x07060302u);
+                xhi.w = __builtin_amdgcn_perm(x[7], x[6], 0x05040100u); xlo.w = __builtin_amdgcn_perm(x[7], x[6], 0x07060302u);
+                mma_ct<T>(acc, whi[st], xhi);
+                mma_ct<T>(acc, whi[st], xlo);
+                mma_ct<T>(acc, wlo[st], xhi);
+            }
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int cl = 8 * qq + 4 * half;
+                const f32x2_t a0 = leaky2((f32x2_t){acc[4 * qq], acc[4 * qq + 1]}, slope);
+                const f32x2_t a1 = leaky2((f32x2_t){acc[4 * qq + 2], acc[4 * qq + 3]}, slope);
+                const float o8[8] = {a0.x, a0.y, a1.x, a1.y, 0.f, 0.f, 0.f, 0.f};
+                const uint4 pk = T::pack(o8);
+                *reinterpret_cast<uint2*>(wl + r * RECP + cl * ES) = make_uint2(pk.x, pk.y);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const unsigned sp = (unsigned)((cur.z * h + cur.y0 + ry) * wd + xs);   // first voxel of the group inside the patch
+#pragma unroll
+            for (int ck = 0; ck < CPT; ++ck) {
+                const uint4 val = *reinterpret_cast<const uint4*>(wl + vv * RECP + (ck * 2 + sub) * 16);
+                buf_store16_counted(val, ors, vv * 32 + sub * 16,
+                                    ((unsigned)(blockIdx.y * CPT + ck) * (unsigned)dhw + sp) * 32u);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (!more) break;
+        park(tile0 + (buf ^ 1) * ((twords + 3) / 4 * 4));   // (waits for the fetched words: they are older than the stores)
+        __syncthreads();
+        buf ^= 1;
+        sidx = snext;
+        cur = nxt;
+    }
+}
+
 // ---- max-pool 2x2x2 ----------------------------------------------------------
 // Grid: x = (volume, output plane), y = blocks of 16-byte pieces of that plane, so
 // small pyramid levels still fill their blocks. Index arithmetic is 32-bit; the
@@ -1046,7 +1211,7 @@ static inline unsigned stream_grid(size_t items) {
 
 int launch_conv_first(int dtype, const float* x, float* xpad, const float* w, const float* bias,
                       void* dst, int n, int d, int h, int wd, int c0p, float slope,
-                      hipStream_t stream) {
+                      hipStream_t stream, bool first_no_strips) {
     const size_t nvox = (size_t)n * d * h * wd;
     constexpr int MT = 4;
     const size_t blocks = (nvox + 4 * MT * 32 - 1) / (4 * MT * 32);
@@ -1069,6 +1234,20 @@ int launch_conv_first(int dtype, const float* x, float* xpad, const float* w, co
     // ROWS variant: whole 32-voxel groups inside a row, one padded / output patch per 32-bit descriptor
     const bool rows = wd % 32 == 0 && (size_t)(d + 2) * (h + 2) * (wd + 2) * 4 < 0x7fffffffULL &&
                       (size_t)c0p * 2 * d * h * wd < 0x7fffffffULL;
+    // row strips when the rows variant applies, a strip is whole rows and the tile fits the staging registers
+    const bool strips = rows && !first_no_strips && h % kStripRows == 0 && 3 * (kStripRows + 2) * (wd + 2) <= 8 * 256;
+    if (strips && dtype != EXASPIM_DT_F32) {
+        const int nstrips = n * d * (h / kStripRows);
+        const size_t tile_bytes = ((size_t)3 * (kStripRows + 2) * (wd + 2) * 4 + 15) / 16 * 16;
+        const size_t lds = 2 * tile_bytes + 4 * 32 * (32 * 2 + 16);
+        dim3 sgrid((unsigned)(nstrips < 1024 ? nstrips : 1024), c0p / 32);
+        if (dtype == EXASPIM_DT_BF16)
+            conv_first16_strip_kernel<BF16T><<<sgrid, 256, lds, stream>>>(xsplit, w, bias, dst, n, d, h, wd, c0p, slope);
+        else
+            conv_first16_strip_kernel<F16T><<<sgrid, 256, lds, stream>>>(xsplit, w, bias, dst, n, d, h, wd, c0p, slope);
+        EXA_CHECK_HIP(hipGetLastError());
+        return EXASPIM_OK;
+    }
     switch (dtype) {
         case EXASPIM_DT_F32:
             conv_first_kernel<F32T, MT><<<grid, 256, 0, stream>>>(xpad, w, bias, dst, (int)nvox, d, h, wd, c0p, slope);

@@ -25,7 +25,6 @@ There is no CPU fallback: a model on a CPU device raises.
 """
 
 import itertools
-import os
 import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -47,6 +46,11 @@ except ImportError:  # pragma: no cover
 # workgroups overlaps another batch's work -- and the result does not change by a bit (stitching
 # stays in batch order on the caller's stream).
 DEFAULT_STREAMS = 3
+# Switches between bit-identical (PLAIN_GATHER) or superset (FULL_PATCHES) execution plans, for the tests that
+# hold the plans to each other and for measurements; module attributes, not environment variables, so nothing
+# outside the calling code can flip them.
+PLAIN_GATHER = False    # True: gather float32 patches and let the engine pad them, instead of the prepared layout
+FULL_PATCHES = False    # True: compute the margin predict() discards as well (exaspim_unet_forward untrimmed)
 
 _VOX_CODES = {
     np.dtype(np.uint8): _native.VOX_U8,
@@ -711,7 +715,7 @@ def _model_probabilities(model, inputs, trim=0, out=None):
     the "trim" voxels next to every patch face, which the caller discards
     (inference.py:161-162), are left undefined."""
     if isinstance(model, UNet3D):
-        if os.environ.get("EXASPIM_FULL_PATCHES"):  # measurement aid: compute the discarded margin too
+        if FULL_PATCHES:  # measurement aid: compute the discarded margin too
             trim = 0
         return model.run(inputs, apply_sigmoid=True, trim=trim, out=out)
     with torch.no_grad():
@@ -831,8 +835,8 @@ def run_sliding_window(volume, model, plan, n_channels, batch_size, brightness_c
         model.resolve_compute_dtype(probe)
         del probe
     prepared_layout = None
-    if isinstance(model, UNet3D) and os.environ.get("EXASPIM_PLAIN_GATHER") != "1":
-        prepared_layout = model.input_layout(device)    # (EXASPIM_PLAIN_GATHER=1: tests hold the two paths to each other)
+    if isinstance(model, UNet3D) and not PLAIN_GATHER:
+        prepared_layout = model.input_layout(device)    # (PLAIN_GATHER: tests hold the two paths to each other)
     for bi, i in enumerate(range(0, len(starts), batch_size)):
         batch = starts_dev[i:i + batch_size]
         worker = workers[bi % n_streams]
@@ -843,7 +847,7 @@ def run_sliding_window(volume, model, plan, n_channels, batch_size, brightness_c
                                            mn=mn, mx=mx, layout=prepared_layout)
                 pred = model.run_prepared(
                     inputs, (int(batch.shape[0]),) + tuple(plan.patch_shape), apply_sigmoid=True,
-                    trim=0 if os.environ.get("EXASPIM_FULL_PATCHES") else plan.trim)
+                    trim=0 if FULL_PATCHES else plan.trim)
             else:
                 inputs = _get_batch_inputs(volume, batch, plan.patch_shape, device, clip=clip,
                                            mn=mn, mx=mx)

@@ -821,7 +821,7 @@ def test_gather_writes_the_first_convolutions_operand_layout(dev, vox, clip):
 @pytest.mark.parametrize("dtype", ["fp32", "fp16", "bf16"])
 def test_prepared_gather_path_does_not_change_a_bit(dev, dtype, monkeypatch):
     """predict() lets the gather kernel write the first convolution's operand layout
-    (exaspim_unet_forward_prepared); EXASPIM_PLAIN_GATHER=1 goes through the float32 batch
+    (exaspim_unet_forward_prepared); inference.PLAIN_GATHER goes through the float32 batch
     and the engine's own padding pass, like model(inputs) does. Same bits."""
     from aind_exaspim_neuron_segmentation_amd import inference
 
@@ -829,7 +829,7 @@ def test_prepared_gather_path_does_not_change_a_bit(dev, dtype, monkeypatch):
     vol = synthetic.synth_volume((72, 88, 104), seed=5)
     kw = dict(batch_size=5, patch_shape=(32, 48, 32), overlap=(8, 8, 8), trim=4, verbose=False)
     fused = inference.predict(vol, model, **kw)
-    monkeypatch.setenv("EXASPIM_PLAIN_GATHER", "1")
+    monkeypatch.setattr(inference, "PLAIN_GATHER", True)
     plain = inference.predict(vol, model, **kw)
-    monkeypatch.delenv("EXASPIM_PLAIN_GATHER")
+    monkeypatch.setattr(inference, "PLAIN_GATHER", False)
     assert fused.any() and np.array_equal(fused, plain)

@@ -147,6 +147,34 @@ def test_bench_launches_its_own_ranks():
     assert bad.returncode != 0
 
 
+def test_bench_on_a_2x2_rank_grid():
+    """Four ranks (the 2 x 2 grid: z and y neighbours and the diagonal one) share the one GPU over gloo:
+    the input halo arrives from three neighbours, bands travel along both axes and the corner is
+    forwarded -- the same line fields, and the same output checksum as with the halo synthesised in place."""
+    import json
+    import subprocess
+    import sys
+
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EXASPIM_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    sums = []
+    for halo in ("exchange", "synth"):
+        out = subprocess.run(
+            [sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--size", "128", "--steps", "1",
+             "--warmup", "0", "--no-cpu-baseline", "--input-halo", halo],
+            env=env, capture_output=True, text=True, timeout=900, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+        assert d["n_gpus"] == 4 and d["config"]["rank_grid_zy"] == [2, 2] and "256x256x128" in d["metric"]
+        assert d["config"]["input_halo"] == halo and (d["config"]["input_halo_ms"] > 0) == (halo == "exchange")
+        sums.append(d["config"]["output_checksum"])
+    assert sums[0] == sums[1] and sums[0] > 0
+
+
 def test_bench_stops_the_other_ranks_when_one_rank_dies():
     """Only rank 1 fails (test hook EXASPIM_BENCH_FAIL_RANK): rank 0 would sit in its first collective
     waiting for it. The launcher polls its children, stops the survivor and exits non-zero -- long
