@@ -193,7 +193,7 @@ static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, in
                                    : const_cast<float*>(static_cast<const float*>(x_prepared)),
                           reinterpret_cast<const float*>(e->packed + p.first_w_off),
                           reinterpret_cast<const float*>(e->packed + p.first_b_off), A(0), n, d,
-                          h, w, p.c0p, kLeakySlope, stream));
+                          h, w, p.c0p, kLeakySlope, stream, (e->options & EXASPIM_OPT_FIRST_PER_GROUP) != 0));
     if (absmax) RUN(launch_absmax(dt, A(0), (size_t)n * d * h * w * p.c0p * dtype_size(dt), absmax, stream));
     RUN(conv(0, A(0), nullptr, skip(0), 0));                      // x1
     for (int l = 1; l <= 4; ++l) {
@@ -428,7 +428,7 @@ extern "C" int exaspim_unet_forward_absmax(exaspim_unet* h, const float* x_dev, 
 
 extern "C" int exaspim_unet_set_options(exaspim_unet* h, uint32_t options) {
     EXA_CHECK_ARG(h != nullptr, "set_options: NULL handle");
-    EXA_CHECK_ARG((options & ~(uint32_t)(EXASPIM_OPT_SEPARATE_POOL | EXASPIM_OPT_SEPARATE_DEEP_POOLS | EXASPIM_OPT_PLAIN_UPSAMPLE)) == 0,
+    EXA_CHECK_ARG((options & ~(uint32_t)(EXASPIM_OPT_SEPARATE_POOL | EXASPIM_OPT_SEPARATE_DEEP_POOLS | EXASPIM_OPT_PLAIN_UPSAMPLE | EXASPIM_OPT_FIRST_PER_GROUP)) == 0,
                   "set_options: unknown option bits 0x%x", options);
     h->options = options;
     return EXASPIM_OK;

@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) void conv_first16_kernel(
 // behind the strip's stores, which hipcc counts (s_waitcnt vmcnt(#stores)). Same operands to the same six
 // MFMAs per group as conv_first16_kernel: same bits.
 constexpr int kStripRows = 4;
-template <typename T>
+template <typename T, int GPW>   // GPW: 32-voxel groups per wave and strip = width / 32
 __global__ __launch_bounds__(256) void conv_first16_strip_kernel(
     const unsigned* __restrict__ xp, const float* __restrict__ w, const float* __restrict__ bias,
     void* __restrict__ dst, int n, int d, int h, int wd, int c0p, float slope) {
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(256) void conv_first16_strip_kernel(
         bq[q] = *reinterpret_cast<const float4*>(bias + co_tile + 8 * q + 4 * half);
 
     // this thread's words of a tile: word i = tid + k * 256 -> (plane, row, x) of the tile
-    constexpr int NLOAD = 8;                       // ceil(3 * 6 * (128 + 2) / 256) covers widths up to 128
+    constexpr int NLOAD = (3 * (R + 2) * (GPW * 32 + 2) + 255) / 256;   // words of a tile per thread (7 at a width of 96)
     unsigned goff[NLOAD];                          // byte offset inside the padded patch relative to the strip origin
 #pragma unroll
     for (int k = 0; k < NLOAD; ++k) {
@@ -667,8 +667,7 @@ __global__ __launch_bounds__(256) void conv_first16_strip_kernel(
     const size_t opatch_bytes = (size_t)(c0p * ES / 32) * dhw * 32;
     const int strips_y = h / R;
     const int nstrips = n * d * strips_y;
-    const int gpr = wd / 32;                       // groups per row
-    const int ngroups = R * gpr;                   // groups per strip
+    const int gpr = wd / 32;                       // groups per row (= GPW: four rows, four waves)
 
     struct Strip { int nb, z, y0; };
     auto locate = [&](int sidx) {
@@ -712,7 +711,9 @@ __global__ __launch_bounds__(256) void conv_first16_strip_kernel(
         const unsigned* const tile = tile0 + buf * ((twords + 3) / 4 * 4);
         const __amdgpu_buffer_rsrc_t ors =
             layer_rsrc(static_cast<char*>(dst) + (size_t)cur.nb * opatch_bytes, opatch_bytes);
-        for (int q = wave; q < ngroups; q += 4) {  // wave-uniform
+#pragma unroll
+        for (int gi = 0; gi < GPW; ++gi) {         // (a compile-time count: hipcc must be able to count the stores)
+            const int q = wave + 4 * gi;
             const int ry = q / gpr, xs = (q - ry * gpr) * 32;
             const int base = ry * trow + xs;
             f32x16_ct acc;
@@ -1235,16 +1236,21 @@ int launch_conv_first(int dtype, const float* x, float* xpad, const float* w, co
     const bool rows = wd % 32 == 0 && (size_t)(d + 2) * (h + 2) * (wd + 2) * 4 < 0x7fffffffULL &&
                       (size_t)c0p * 2 * d * h * wd < 0x7fffffffULL;
     // row strips when the rows variant applies, a strip is whole rows and the tile fits the staging registers
-    const bool strips = rows && !first_no_strips && h % kStripRows == 0 && 3 * (kStripRows + 2) * (wd + 2) <= 8 * 256;
+    const bool strips = rows && !first_no_strips && h % kStripRows == 0 && wd <= 128;
     if (strips && dtype != EXASPIM_DT_F32) {
         const int nstrips = n * d * (h / kStripRows);
         const size_t tile_bytes = ((size_t)3 * (kStripRows + 2) * (wd + 2) * 4 + 15) / 16 * 16;
         const size_t lds = 2 * tile_bytes + 4 * 32 * (32 * 2 + 16);
         dim3 sgrid((unsigned)(nstrips < 1024 ? nstrips : 1024), c0p / 32);
-        if (dtype == EXASPIM_DT_BF16)
-            conv_first16_strip_kernel<BF16T><<<sgrid, 256, lds, stream>>>(xsplit, w, bias, dst, n, d, h, wd, c0p, slope);
-        else
-            conv_first16_strip_kernel<F16T><<<sgrid, 256, lds, stream>>>(xsplit, w, bias, dst, n, d, h, wd, c0p, slope);
+#define STRIP(TT, GG) conv_first16_strip_kernel<TT, GG><<<sgrid, 256, lds, stream>>>(xsplit, w, bias, dst, n, d, h, wd, c0p, slope)
+        const bool bf = dtype == EXASPIM_DT_BF16;
+        switch (wd / 32) {
+            case 1: if (bf) STRIP(BF16T, 1); else STRIP(F16T, 1); break;
+            case 2: if (bf) STRIP(BF16T, 2); else STRIP(F16T, 2); break;
+            case 3: if (bf) STRIP(BF16T, 3); else STRIP(F16T, 3); break;
+            default: if (bf) STRIP(BF16T, 4); else STRIP(F16T, 4); break;
+        }
+#undef STRIP
         EXA_CHECK_HIP(hipGetLastError());
         return EXASPIM_OK;
     }

@@ -778,6 +778,30 @@ def test_pipelined_upsampling_equals_the_plain_kernel(dev, oracle, dtype, wm, sh
     assert np.array_equal(piped, plain)
 
 
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("wm,shape,n", [(1, (96, 96, 96), 3), (1, (16, 32, 64), 5), (2, (32, 48, 128), 2), (0.5, (48, 16, 32), 7),
+                                        (1, (32, 32, 160), 1), (1, (32, 16, 48), 2)])
+def test_row_strip_first_convolution_equals_the_per_group_kernel(dev, oracle, dtype, wm, shape, n):
+    """inc.0 of the 16-bit modes (Conv3d(1 -> C0), unet3d.py:64,143-145) runs on row strips -- four rows x the
+    whole width per workgroup, the taps' input words staged once in LDS -- whenever the width is a multiple of
+    32 up to 128; the engine option EXASPIM_OPT_FIRST_PER_GROUP keeps the kernel that loads 16 taps per
+    32-voxel group. Same operands to the same MFMAs: the logits must be the same bits (widths 32 / 64 / 96 /
+    128 = one to four groups per wave, two cout slices, and shapes where the strip kernel does not apply)."""
+    from aind_exaspim_neuron_segmentation_amd import _native
+    from aind_exaspim_neuron_segmentation_amd.machine_learning.unet3d import UNet3D
+
+    sd = synthetic.synth_state_dict(3, wm, seed=41)
+    model = UNet3D(output_channels=3, width_multiplier=wm, compute_dtype=dtype)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    model = model.to(dev).eval()
+    x = normalized_input(oracle, shape, seed=43, n=n).to(dev)
+    strips = model(x).cpu().numpy()
+    model.engine_options = _native.OPT_FIRST_PER_GROUP
+    groups = model(x).cpu().numpy()
+    model.engine_options = 0
+    assert np.isfinite(strips).all() and np.array_equal(strips, groups)
+
+
 def _split_words(x, kind):
     """hi | lo << 16 of float32 values, hi = half(x), lo = half(x - float(hi)) (numpy)."""
     if kind == "f16":

@@ -135,6 +135,6 @@ int main(int argc, char** argv) {
     time("maxpool 64ch 48->24", 16.0 * 128 * (48.0 * 48 * 48 + 24 * 24 * 24),
          [&] { launch_maxpool2(dt, a, b, n, 48, 48, 48, 64, 0); });
     time("inc.0 (pad + conv_first16) 96^3 -> 32ch", 16.0 * 96 * 96 * 96 * (4 + 64),
-         [&] { launch_conv_first(dt, x, xp, w, bias, b, n, 96, 96, 96, 32, 0.01f, 0); });
+         [&] { launch_conv_first(dt, x, xp, w, bias, b, n, 96, 96, 96, 32, 0.01f, 0, getenv("EXASPIM_NO_STRIPS") != nullptr); });
     return 0;
 }

@@ -26,6 +26,7 @@ p.add_argument("--dtype", default="fp16")
 p.add_argument("--batch", type=int, default=16)
 p.add_argument("--streams", type=int, default=1)
 p.add_argument("--mask", type=lambda s: int(s, 0), default=0x1FFFF)
+p.add_argument("--options", type=lambda s: int(s, 0), default=0, help="engine option bits (_native.OPT_*)")
 a = p.parse_args()
 
 dev = torch.device("cuda:0")
@@ -33,6 +34,7 @@ sd = synthetic.synth_state_dict(3, 1, seed=1)
 model = UNet3D(output_channels=3, compute_dtype=a.dtype)
 model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
 model.to(dev).eval()
+model.engine_options = a.options
 shape = (a.size,) * 3
 vol_t = torch.empty(shape, dtype=torch.int16, device=dev)
 blk = _native.Block.make(shape, (0, 0, 0), shape)
