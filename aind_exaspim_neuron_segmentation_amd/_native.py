@@ -16,6 +16,7 @@ VOX_U8, VOX_U16, VOX_I16, VOX_F32, VOX_F64 = 0, 1, 2, 3, 4
 IN_F32, IN_PADDED_F32, IN_PADDED_SPLIT_F16, IN_PADDED_SPLIT_BF16 = 0, 1, 2, 3   # EXASPIM_IN_*
 UP_CONVT = 0x100   # EXASPIM_UP_CONVT: OR into a dtype code for UNet3D(trilinear=False)
 OPT_SEPARATE_POOL, OPT_SEPARATE_DEEP_POOLS, OPT_PLAIN_UPSAMPLE, OPT_FIRST_PER_GROUP = 1, 2, 4, 8   # EXASPIM_OPT_*
+OPT_UPSAMPLE_PER_THREAD = 16
 
 DTYPE_CODES = {
     "fp32": DT_F32, "float32": DT_F32, "f32": DT_F32,

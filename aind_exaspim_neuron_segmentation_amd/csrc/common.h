@@ -230,7 +230,7 @@ int launch_maxpool2(int dtype, const void* src, void* dst, int n, int d, int h, 
                     int c, hipStream_t stream);  // d,h,w = INPUT size
 // d,h,w = INPUT size; output voxels within "margin" of a face are not computed
 int launch_upsample2(int dtype, const void* src, void* dst, int n, int d, int h, int w,
-                     int c, int margin, hipStream_t stream, bool plain_kernel = false);
+                     int c, int margin, hipStream_t stream, bool plain_kernel = false, bool per_thread = false);
 // *out = max(*out, largest |value| in the tensor) as float bits (out zeroed by the caller)
 int launch_absmax(int dtype, const void* src, size_t bytes, float* out, hipStream_t stream);
 int launch_head(int dtype, const void* src, const float* w, const float* bias,

@@ -2051,6 +2051,8 @@ static int launch_zpipe(const ConvArgs& a, hipStream_t stream) {
     if (wgs > blocks) wgs = blocks;
 #ifdef EXASPIM_TRACE
     if (g_variant >= 10 && g_variant < 20) wgs = blocks;
+    // (tools/conv_trace.hip: one workgroup per CU shows what a wave's tap loop does with the matrix pipe to itself)
+    if (const char* e = getenv("EXASPIM_TRACE_WGS_PER_CU")) wgs = resident_workgroups(1) * (long long)atoi(e) / slices / 8 * 8;
 #endif
     dim3 grid((unsigned)wgs, slices);
     conv3x3x3_zpipe<Tag, TZ, TY, TX, MINW, D, HEAD, POOL><<<grid, TY * TX * 2, 0, stream>>>(a, tz, ty, tx);

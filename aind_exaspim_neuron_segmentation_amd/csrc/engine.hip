@@ -222,7 +222,8 @@ static int forward(exaspim_unet* e, const float* x, float* out, int n, int d, in
             // up4.0 reads the upsampled tensor one voxel beyond its own trimmed output
             RUN(launch_upsample2(dt, prev, A(l), n, d >> (l + 1), h >> (l + 1), w >> (l + 1), L0.cb,
                                  trimmed && l == 0 && trim > 2 ? trim - 2 : 0, stream,
-                                 (e->options & EXASPIM_OPT_PLAIN_UPSAMPLE) != 0));
+                                 (e->options & EXASPIM_OPT_PLAIN_UPSAMPLE) != 0,
+                                 (e->options & EXASPIM_OPT_UPSAMPLE_PER_THREAD) != 0));
         }
         RUN(conv(i0, skip(l), A(l), B(l), l));
         RUN(conv(i0 + 1, B(l), nullptr, A(l), l));
@@ -428,7 +429,8 @@ extern "C" int exaspim_unet_forward_absmax(exaspim_unet* h, const float* x_dev, 
 
 extern "C" int exaspim_unet_set_options(exaspim_unet* h, uint32_t options) {
     EXA_CHECK_ARG(h != nullptr, "set_options: NULL handle");
-    EXA_CHECK_ARG((options & ~(uint32_t)(EXASPIM_OPT_SEPARATE_POOL | EXASPIM_OPT_SEPARATE_DEEP_POOLS | EXASPIM_OPT_PLAIN_UPSAMPLE | EXASPIM_OPT_FIRST_PER_GROUP)) == 0,
+    EXA_CHECK_ARG((options & ~(uint32_t)(EXASPIM_OPT_SEPARATE_POOL | EXASPIM_OPT_SEPARATE_DEEP_POOLS | EXASPIM_OPT_PLAIN_UPSAMPLE | EXASPIM_OPT_FIRST_PER_GROUP |
+                                          EXASPIM_OPT_UPSAMPLE_PER_THREAD)) == 0,
                   "set_options: unknown option bits 0x%x", options);
     h->options = options;
     return EXASPIM_OK;

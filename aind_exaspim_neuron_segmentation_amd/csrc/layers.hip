@@ -1122,6 +1122,218 @@ __global__ __launch_bounds__(256, UPS_MINW) void upsample2_pipe_kernel(const uin
     }
 }
 
+// The same interpolation with the SOURCE rows of a workgroup shared through LDS and a wave of its own to
+// fetch them (r03). In the per-thread pipeline above every thread fetches its own six pieces of the new
+// source plane -- 1 536 loads per workgroup and plane for at most 480 distinct pieces -- and waits for them
+// in the wave that also stores (vector memory operations retire in order, one counter for loads and stores
+// on gfx9: that wait is also a wait for every older store). Here a workgroup is five waves. Waves 0-3
+// (256 threads = 256 consecutive (row pair, x, group) items = up to three row pairs) only read LDS,
+// interpolate and store; they never wait on the vector memory counter. Wave 4 only loads: the contiguous
+// run of source rows the workgroup shares is at most 512 pieces per plane (eight loads per lane),
+// fetched kUpsAhead planes ahead into registers and parked in one of four LDS slots the step before it
+// is read. One s_barrier per step keeps the two sides one plane apart (no vmcnt(0) at a workgroup barrier
+// on gfx950). Step t: wave 4 parks plane p0 - 2 + t; waves 0-3 interpolate plane p0 - 3 + t (t >= 1) and,
+// from t = 4 on, emit pair p0 + t - 4, whose newest plane that is. Needs the regular schedule, a first
+// pair >= 2 (no pairs that do not advance) and a whole number of runs; same arithmetic in the same order
+// as upsample2_kernel, bit for bit.
+// Measured (level-0 launch of the trimmed forward, batch 16; tools/layer_bench.hip, tools/store_ceiling.hip,
+// UPS_ABLATE): stand-alone 208-215 us against 247-261 us for the per-thread pipeline on the same box; the
+// bare stores of this pattern take 147 us, compute + LDS 81 us, compute + loads 87 us, compute + stores
+// 157-170 us. The same four numbers came out with the loads in the storing waves (prefetch 2 ... 8 planes
+// deep: 222 ... 204 us), so what the loads cost on top of the stores is not the shared counter but the
+// memory system serving reads between the writes; inside a step, where the source was written by the
+// launch before, the kernel takes 170 us (rocprofv3) against 209 us for the per-thread pipeline.
+#ifndef UPS_AHEAD
+#define UPS_AHEAD 3
+#endif
+#ifndef UPS_ABLATE
+#define UPS_ABLATE 0   // measurement aid: 1 = no global loads, 2 = every store dropped by its range check
+#endif
+constexpr int kUpsAhead = UPS_AHEAD;
+constexpr int kUpsSlotPieces = 512;     // 16-byte pieces of one LDS plane slot (eight per lane of the loading wave)
+
+template <typename T, int RUN>
+__global__ __launch_bounds__(320) void upsample2_strip_kernel(const uint4* __restrict__ src,
+                                                       uint4* __restrict__ dst, int d, int h,
+                                                       int w, float sz, float sy, float sx,
+                                                       int margin) {
+    constexpr int cg = 2;
+    constexpr int NP = T::kG / 2;
+    constexpr int A = kUpsAhead;
+    constexpr int STEPS = RUN + 4;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    __shared__ uint4 slots[4][kUpsSlotPieces];
+    const int od = d * 2, oh = h * 2, ow = w * 2;
+    const int nz = od - 2 * margin, ny = oh - 2 * margin, nx = ow - 2 * margin;
+    const int nzp = (nz + 1) >> 1, nyp = (ny + 1) >> 1;
+    const int nruns = nzp / RUN;                 // (the launcher checks nzp % RUN == 0)
+    const int nb = blockIdx.x / nruns, run = blockIdx.x - nb * nruns;
+    const int pr0 = run * RUN;
+    const int p0 = (margin >> 1) + pr0;         // >= 2: pair p wants planes (p - 1, p, p + 1)
+    // the workgroup's source rows start at the first item's first row
+    const int yp_first = (int)((blockIdx.y * 256u) >> 1) / nx;
+    int rmin, r1;
+    float l1;
+    lerp_coord(margin + 2 * yp_first, h, sy, rmin, r1, l1);
+    const unsigned image0 = (unsigned)(rmin * w * cg);           // first piece of the image inside a source plane
+    const size_t splane = (size_t)h * w * cg * 16;
+    // both sides synchronise with the bare barrier instruction: LDS traffic settled (lgkmcnt), nothing else
+    auto step_barrier = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+
+    if (threadIdx.x >= 256) {
+        // ---- wave 4: global -> registers -> LDS, nothing else
+        const int lane = threadIdx.x - 256;
+        const __amdgpu_buffer_rsrc_t srs = layer_rsrc(reinterpret_cast<const char*>(src) + (size_t)nb * d * splane,
+                                                      (size_t)d * splane);
+        unsigned gpos[8];                          // byte offsets inside a plane; past the plane: dropped
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned piece = image0 + lane + 64u * k;
+            gpos[k] = piece < (unsigned)(h * w * cg) ? piece * 16u : 0x80000000u;
+        }
+        struct Eight { uint4 v[8]; };
+        auto fetch = [&](int p) {                  // the image of source plane p (clamped)
+            Eight r;
+            const unsigned so = (unsigned)(p < d - 1 ? p : d - 1) * (unsigned)splane;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+#if UPS_ABLATE & 1
+                r.v[k] = make_uint4(so, gpos[k], 0, 0);
+#else
+                const u32x4_b t = __builtin_amdgcn_raw_buffer_load_b128(srs, (int)gpos[k], (int)so, 0);
+                r.v[k] = make_uint4(t.x, t.y, t.z, t.w);
+#endif
+            }
+            return r;
+        };
+        Eight fl[A];
+#pragma unroll
+        for (int k = 0; k < A; ++k) fl[k] = fetch(p0 - 2 + k);
+#pragma unroll
+        for (int t = 0; t < STEPS; ++t) {
+            if (t < STEPS - 1) {                   // (the last step has nothing left to park)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) slots[(p0 - 2 + t) & 3][lane + 64 * k] = fl[t % A].v[k];
+                if (t + A < STEPS - 1) fl[t % A] = fetch(p0 - 2 + t + A);
+            }
+            step_barrier();
+        }
+        return;
+    }
+
+    // ---- waves 0-3: LDS -> interpolation -> stores
+    const int nitems = nyp * nx * cg;
+    const unsigned item = blockIdx.y * 256u + threadIdx.x;
+    const bool live = item < (unsigned)nitems;
+    const unsigned it = live ? item : (unsigned)nitems - 1u;
+    const int g = it & 1;
+    const int yp = (int)(it >> 1) / nx, x = margin + (int)(it >> 1) - yp * nx;
+    const int ya = margin + 2 * yp;
+    const bool has_yb = ya + 1 < oh - margin;
+    const LerpPair py = lerp_pair(ya, has_yb, h, sy);
+    int x0, x1;
+    float lx;
+    lerp_coord(x, w, sx, x0, x1, lx);
+    const f2 wx0 = {1.f - lx, 1.f - lx}, wx1 = {lx, lx};
+    // this thread's six pieces inside a slot
+    const unsigned lpos[3][2] = {{(unsigned)((py.s0 * w + x0) * cg + g) - image0, (unsigned)((py.s0 * w + x1) * cg + g) - image0},
+                                 {(unsigned)((py.s1 * w + x0) * cg + g) - image0, (unsigned)((py.s1 * w + x1) * cg + g) - image0},
+                                 {(unsigned)((py.s2 * w + x0) * cg + g) - image0, (unsigned)((py.s2 * w + x1) * cg + g) - image0}};
+    const float yA[3] = {py.a0, py.a1, 0.f}, yB[3] = {py.b0, py.b1, py.b2};
+    const size_t oplane = (size_t)oh * ow * cg * 16;
+    char* const obase = reinterpret_cast<char*>(dst) + (size_t)nb * od * oplane;
+    const unsigned orow[2] = {live ? (unsigned)(((ya + 0) * ow + x) * cg + g) * 16u : 0x80000000u,
+                              live && has_yb ? (unsigned)(((ya + 1) * ow + x) * cg + g) * 16u : 0x80000000u};
+
+    auto interp = [&](int p, f2 (*q)[NP]) {        // x and y interpolation of plane p, as upsample2_kernel's load_plane
+        const uint4* const sl = slots[p & 3];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            float v0[T::kG], v1[T::kG];
+            T::unpack(sl[lpos[rr][0]], v0);
+            T::unpack(sl[lpos[rr][1]], v1);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const f2 xr = __builtin_elementwise_fma(wx1, (f2){v1[2 * j], v1[2 * j + 1]},
+                                                        wx0 * (f2){v0[2 * j], v0[2 * j + 1]});
+                const f2 wa = {yA[rr], yA[rr]}, wb = {yB[rr], yB[rr]};
+                if (rr == 0) {
+                    q[0][j] = wa * xr;
+                    q[1][j] = wb * xr;
+                } else {
+                    if (rr == 1) q[0][j] = __builtin_elementwise_fma(wa, xr, q[0][j]);
+                    q[1][j] = __builtin_elementwise_fma(wb, xr, q[1][j]);
+                }
+            }
+        }
+    };
+    auto emit_pair = [&](int za, const LerpPair& pz, const f2 (*v0)[NP], const f2 (*v1)[NP], const f2 (*v2)[NP]) {
+        const bool has_zb = za + 1 < od - margin;
+#pragma unroll
+        for (int zz = 0; zz < 2; ++zz) {
+            const __amdgpu_buffer_rsrc_t ors =
+                layer_rsrc(obase, ((UPS_ABLATE & 2) ? d < 0 : true) && (zz == 0 || has_zb) ? (size_t)od * oplane : (size_t)0);
+#pragma unroll
+            for (int yy = 0; yy < 2; ++yy) {
+                float out[T::kG];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const f2 o = zz == 0
+                        ? __builtin_elementwise_fma((f2){pz.a1, pz.a1}, v1[yy][j], (f2){pz.a0, pz.a0} * v0[yy][j])
+                        : __builtin_elementwise_fma((f2){pz.b2, pz.b2}, v2[yy][j],
+                              __builtin_elementwise_fma((f2){pz.b1, pz.b1}, v1[yy][j], (f2){pz.b0, pz.b0} * v0[yy][j]));
+                    out[2 * j] = o.x; out[2 * j + 1] = o.y;
+                }
+                buf_store16_counted(T::pack(out), ors, orow[yy], (unsigned)(za + zz) * (unsigned)oplane);
+            }
+        }
+    };
+
+    f2 q0[2][NP], q1[2][NP], q2[2][NP];
+#pragma unroll
+    for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) q0[yy][j] = q1[yy][j] = q2[yy][j] = (f2){0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < STEPS; ++t) {
+        if (t >= 1) {
+#pragma unroll
+            for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+                for (int j = 0; j < NP; ++j) { q0[yy][j] = q1[yy][j]; q1[yy][j] = q2[yy][j]; }
+            interp(p0 - 3 + t, q2);
+        }
+        if (t >= 4) {
+            const int za = margin + 2 * (pr0 + t - 4);
+            const LerpPair pz = lerp_pair(za, za + 1 < od - margin, d, sz);
+            emit_pair(za, pz, q0, q1, q2);
+        }
+        step_barrier();
+    }
+}
+
+// rows of source a workgroup of upsample2_strip_kernel shares, over all its workgroups (host copy of the
+// kernel's float arithmetic)
+static int upsample_strip_rows(int h, int w, int margin, float sy) {
+    const int oh = 2 * h, ny = oh - 2 * margin, nx = 2 * w - 2 * margin;
+    const int nyp = (ny + 1) / 2, nitems = nyp * nx * 2;
+    auto i0 = [&](int o) { const int v = (int)floorf(sy * (float)o); return v < h - 1 ? v : h - 1; };
+    int rows = 0;
+    for (int first = 0; first < nitems; first += 256) {
+        const int last = (first + 255 < nitems ? first + 255 : nitems - 1);
+        const int ypf = (first >> 1) / nx, ypl = (last >> 1) / nx;
+        const int lo = i0(margin + 2 * ypf);
+        int hi = i0(margin + 2 * ypl) + 2;
+        if (hi > h - 1) hi = h - 1;
+        if (hi - lo + 1 > rows) rows = hi - lo + 1;
+    }
+    return rows;
+}
+
 // does pair p of a x2 upsampling of n planes read source planes max(p - 1, 0) .. + 2, in float arithmetic too?
 static bool upsample_schedule_is_regular(int n, float scale) {
     for (int p = 0; p < n; ++p) {
@@ -1305,7 +1517,7 @@ int launch_maxpool2(int dtype, const void* src, void* dst, int n, int d, int h, 
 }
 
 int launch_upsample2(int dtype, const void* src, void* dst, int n, int d, int h, int w,
-                     int c, int margin, hipStream_t stream, bool plain_kernel) {
+                     int c, int margin, hipStream_t stream, bool plain_kernel, bool per_thread) {
     if (margin < 0 || margin >= d || margin >= h || margin >= w) margin = 0;
     const int nv = n * (c * dtype_size(dtype) / 32);   // chunk planes = independent volumes
     // items of one pair of output planes: (row pair, column, 16-byte group)
@@ -1322,6 +1534,22 @@ int launch_upsample2(int dtype, const void* src, void* dst, int n, int d, int h,
     // hold the two kernels to each other bit for bit)
     const bool pipe = !plain_kernel && margin % 2 == 0 && d >= 3 && upsample_schedule_is_regular(d, scale(d)) &&
                       (size_t)8 * d * h * w * 32 < 0x7fffffffULL;
+    // ... and with the workgroup's source rows shared through LDS when, on top of that, no pair of the launch
+    // is one of the two that do not advance, the pairs are a whole number of runs and the rows fit a slot
+    // ("per_thread", EXASPIM_OPT_UPSAMPLE_PER_THREAD: the per-thread pipeline instead, for the tests)
+    if (pipe && !per_thread && margin >= 4 && upsample_strip_rows(h, w, margin, scale(h)) * w * 2 <= kUpsSlotPieces) {
+        const int run = nzp % 14 == 0 ? 14 : nzp % 12 == 0 ? 12 : 0;
+        if (run) {
+            dim3 sgrid((unsigned)(nv * (nzp / run)), (unsigned)((items + 255) / 256));
+#define UPS_STRIP(RR) DISPATCH_T(dtype, (upsample2_strip_kernel<T, RR><<<sgrid, 320, 0, stream>>>(   \
+                          static_cast<const uint4*>(src), static_cast<uint4*>(dst), d, h, w, scale(d), \
+                          scale(h), scale(w), margin)))
+            if (run == 14) { UPS_STRIP(14); } else { UPS_STRIP(12); }
+#undef UPS_STRIP
+            EXA_CHECK_HIP(hipGetLastError());
+            return EXASPIM_OK;
+        }
+    }
     if (pipe) {
         DISPATCH_T(dtype, (upsample2_pipe_kernel<T><<<grid, 256, 0, stream>>>(
                               static_cast<const uint4*>(src), static_cast<uint4*>(dst), d, h, w,

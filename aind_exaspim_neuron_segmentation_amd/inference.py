@@ -559,7 +559,17 @@ def _effective_clip(np_dtype, brightness_clip, storage_dtype=None):
     probe = np.minimum(np.zeros(1, dtype=np_dtype), brightness_clip)  # may raise like numpy
     if probe.dtype == np_dtype:
         return np_dtype.type(brightness_clip), np_dtype
+    if probe.dtype.kind in "iu" and np_dtype.kind in "iu":
+        # a typed integer clip (np.int64(1000) on a uint16 image): numpy widens the image, every voxel
+        # keeps its value, so the comparison can stay in the image's own dtype; the wider dtype only
+        # decides the integer arithmetic inside np.percentile (value_dtype)
+        info, c = np.iinfo(np_dtype), int(brightness_clip)
+        if c < info.min:
+            raise NotImplementedError(f"brightness_clip {brightness_clip!r} lies below every {np_dtype} voxel")
+        return (None if c >= info.max else np_dtype.type(c)), probe.dtype
     if probe.dtype != np.float64:
+        # a float16 / float32 typed clip on a narrow integer image: np.percentile and the
+        # normalisation would then run in that float type's arithmetic
         raise NotImplementedError(
             f"brightness_clip {brightness_clip!r} promotes {np_dtype} voxels to {probe.dtype}"
         )

@@ -180,6 +180,7 @@ int exaspim_unet_forward_absmax(exaspim_unet* h, const float* x_dev, float* out_
 #define EXASPIM_OPT_SEPARATE_DEEP_POOLS 2u
 #define EXASPIM_OPT_PLAIN_UPSAMPLE 4u /* trilinear x2 on the un-pipelined kernel (same bits) */
 #define EXASPIM_OPT_FIRST_PER_GROUP 8u /* inc.0 of the 16-bit modes group by group instead of on row strips (same bits) */
+#define EXASPIM_OPT_UPSAMPLE_PER_THREAD 16u /* trimmed level-0 upsampling: per-thread pipeline instead of shared source rows (same bits) */
 int exaspim_unet_set_options(exaspim_unet* h, uint32_t options);
 
 /* Measurement hooks (bench.py's roofline leg). timing_begin arms HIP-event

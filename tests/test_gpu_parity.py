@@ -581,7 +581,9 @@ def test_predict_voxel_dtypes_vs_oracle(dev, oracle, name, clip):
 
 @pytest.mark.parametrize("name,clip", [("i32", 1000), ("u32", 700), ("i64", 1000), ("u64", 900), ("f64", 123.5),
                                        ("i8", 100), ("u16_fractional_clip", 1000.5), ("u8_fractional_clip", 200.25),
-                                       ("i32_fractional_clip", 800.5)])
+                                       ("i32_fractional_clip", 800.5),
+                                       ("u16_typed_clip", np.int64(1000)), ("i16_wide_range", np.int32(40000)),
+                                       ("i32", np.int64(650))])
 def test_predict_takes_the_dtypes_the_reference_takes(dev, oracle, name, clip):
     """inference.py:79-80 runs on any numeric array: wider integers and float64 travel to
     the device as float32 when the array shows that float32 holds every value (as float64
@@ -601,6 +603,10 @@ def test_predict_takes_the_dtypes_the_reference_takes(dev, oracle, name, clip):
         "u16_fractional_clip": base,
         "u8_fractional_clip": (base % 251).astype(np.uint8),
         "i32_fractional_clip": base.astype(np.int32) - 300,
+        # a typed integer clip widens the image in np.minimum: the same voxels, wider arithmetic in
+        # np.percentile (an int16 difference of order statistics 60 000 apart would wrap)
+        "u16_typed_clip": base,
+        "i16_wide_range": (base.astype(np.int32) * 32 - 32000).astype(np.int16),
     }[name]
     model, sd = make_model(dev)
     kw = dict(batch_size=4, patch_shape=(32, 32, 32), overlap=(16, 8, 8), trim=4,
@@ -752,7 +758,8 @@ def test_fused_max_pool_equals_the_separate_launch(dev, oracle, dtype, wm, shape
 @pytest.mark.parametrize("dtype", ["fp16", "bf16", "fp32"])
 @pytest.mark.parametrize("wm,shape,n,trim", [(1, (96, 96, 96), 2, 8), (1, (96, 96, 96), 1, 0), (1, (48, 64, 80), 3, 4),
                                              (0.5, (32, 48, 64), 2, 6), (2, (16, 32, 48), 1, 2), (1, (96, 96, 96), 1, 7),
-                                             (0.25, (96, 32, 16), 5, 0)])
+                                             (0.25, (96, 32, 16), 5, 0), (1, (64, 80, 96), 2, 6),
+                                             (0.5, (96, 32, 128), 1, 8)])
 def test_pipelined_upsampling_equals_the_plain_kernel(dev, oracle, dtype, wm, shape, n, trim):
     """nn.Upsample(x2, trilinear, align_corners=True) (unet3d.py:248-250) runs on a software-pipelined
     kernel whenever the first output plane it has to produce is even (every level of the full forward; the
@@ -760,7 +767,11 @@ def test_pipelined_upsampling_equals_the_plain_kernel(dev, oracle, dtype, wm, sh
     fetched a pair ahead, branch-free range-checked stores. The engine option EXASPIM_OPT_PLAIN_UPSAMPLE
     runs the plain kernel instead: same arithmetic in the same order, so the same bits -- over the pyramid
     levels of several patch shapes (96/48/24/12, 80/40/20/10 ... wide; source depths down to 1 plane, where
-    the plain kernel is the only one), widths, dtypes, and odd trims (plain kernel either way)."""
+    the plain kernel is the only one), widths, dtypes, and odd trims (plain kernel either way).
+    The trimmed forward's level 0 (margin >= 4, a whole number of 14- or 12-pair runs, source rows of a
+    workgroup within 512 pieces: 96^3 / trim 8, 32x48x64 / trim 6, 64x80x96 / trim 6) goes one step further
+    and shares a workgroup's source rows through LDS (upsample2_strip_kernel); EXASPIM_OPT_UPSAMPLE_PER_THREAD
+    keeps the per-thread pipeline. All three must produce the same bits."""
     from aind_exaspim_neuron_segmentation_amd import _native
     from aind_exaspim_neuron_segmentation_amd.machine_learning.unet3d import UNet3D
 
@@ -771,11 +782,14 @@ def test_pipelined_upsampling_equals_the_plain_kernel(dev, oracle, dtype, wm, sh
     x = normalized_input(oracle, shape, seed=37, n=n).to(dev)
     inner = (Ellipsis,) + ((slice(trim, -trim),) * 3 if trim else (slice(None),) * 3)
     piped = model.run(x, apply_sigmoid=True, trim=trim)[inner].cpu().numpy()
+    model.engine_options = _native.OPT_UPSAMPLE_PER_THREAD
+    per_thread = model.run(x, apply_sigmoid=True, trim=trim)[inner].cpu().numpy()
     model.engine_options = _native.OPT_PLAIN_UPSAMPLE
     plain = model.run(x, apply_sigmoid=True, trim=trim)[inner].cpu().numpy()
     model.engine_options = 0
     assert np.isfinite(piped).all()
     assert np.array_equal(piped, plain)
+    assert np.array_equal(per_thread, plain)
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])

@@ -342,6 +342,23 @@ def test_dtype_rules_and_fractional_clip_percentiles_on_the_host():
     with pytest.raises(NotImplementedError):      # an int32 image forced onto the float32 carrier; 0.1 is not a float32 number
         inf._effective_clip(np.int32, 0.1, np.float32)
     assert inf._effective_clip(np.int32, 0.1, np.float64) == (np.float64(0.1), np.dtype(np.float64))
+    # typed integer clips widen the image in np.minimum; the voxels and the comparison stay as they are
+    assert inf._effective_clip(np.uint16, np.int64(1000)) == (np.uint16(1000), np.dtype(np.int64))
+    assert inf._effective_clip(np.int16, np.int32(40000)) == (None, np.dtype(np.int32))
+    assert inf._effective_clip(np.uint8, np.int16(255)) == (None, np.dtype(np.int16))
+    with pytest.raises(NotImplementedError):      # everything would become the clip
+        inf._effective_clip(np.uint16, np.int32(-5))
+    with pytest.raises(NotImplementedError):      # float32 arithmetic in np.percentile and normalize
+        inf._effective_clip(np.uint16, np.float32(5))
+    # an int16 image whose order statistics lie more than 32767 apart: numpy's own int16 lerp wraps,
+    # the widened one does not -- value_dtype carries that difference
+    wide = np.array([-30000, -30000, 30000, 30000], dtype=np.int16)
+    for c in (np.int32(40000), 32767):
+        cc, vdt = inf._effective_clip(np.int16, c)
+        st = img_util.OrderStatistics(np.bincount(wide.astype(np.int64) + 32768, minlength=65536),
+                                      lambda b: vdt.type(b - 32768))
+        np.testing.assert_array_equal(img_util.percentiles_from_statistics(st, (40, 60), vdt),
+                                      np.percentile(np.minimum(wide, c), (40, 60)))
 
     vol = synthetic.synth_volume((24, 20, 28), seed=5)
     for clip in (1000.5, 37.25, 5000.75):

@@ -124,6 +124,8 @@ int main(int argc, char** argv) {
     // up4.up: 32 ch, 48^3 -> 96^3, margin 6 (trimmed forward) and 0
     time("upsample 32ch 48->96 margin 6", 16.0 * 64 * (84.0 * 84 * 84 + 48 * 48 * 48),
          [&] { launch_upsample2(dt, a, b, n, 48, 48, 48, 32, 6, 0, plain); });
+    time("upsample 32ch 48->96 margin 6, per-thread pipeline", 16.0 * 64 * (84.0 * 84 * 84 + 48 * 48 * 48),
+         [&] { launch_upsample2(dt, a, b, n, 48, 48, 48, 32, 6, 0, plain, true); });
     time("upsample 32ch 48->96 margin 0", 16.0 * 64 * (96.0 * 96 * 96 + 48 * 48 * 48),
          [&] { launch_upsample2(dt, a, b, n, 48, 48, 48, 32, 0, 0, plain); });
     time("upsample 64ch 24->48", 16.0 * 128 * (48.0 * 48 * 48 + 24 * 24 * 24),
