@@ -779,8 +779,8 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
     constexpr int LDS_UNITS = XUNITS + WUNITS;
     constexpr int NS = 9 * HZ;             // steps per chunk
     constexpr int R = D + 1;               // operand ring
-#ifndef EXASPIM_HEAD_TZ5
-#define EXASPIM_HEAD_TZ5 1   // (0: the 6-plane tiles of every other z-column launch, for A/B builds)
+#ifndef EXASPIM_HEAD_TZ
+#define EXASPIM_HEAD_TZ 5   // planes per tile of the trimmed fused-head launch (0: the 6-plane tiles of every other launch; A/B builds)
 #endif
 #ifndef EXASPIM_LOAD_STRIDE
 // stride 1 / 2 / 3 inside a 1024^3 step (us per launch, same box): up3.3 + up4.0 510 / 490 / 496,
@@ -2261,16 +2261,16 @@ static int launch_typed(const ConvArgs& a, hipStream_t stream) {
                 }
             }
 #endif
-#if EXASPIM_HEAD_TZ5
+#if EXASPIM_HEAD_TZ
             // the fused-head launch of the trimmed forward covers 80 planes: 16 tiles of 5 instead of 14 of 6
             // (4.8 % fewer planes; up4.3 459 -> 439 us inside 512^3 steps, same bits: a voxel's taps and
             // chunks accumulate in the same order whatever the tile)
-            if (a.head_out && a.cout == 32 && a.ext[0] % 6 != 0 && a.ext[0] % 5 == 0) {
+            if (a.head_out && a.cout == 32 && a.ext[0] % 6 != 0 && a.ext[0] % EXASPIM_HEAD_TZ == 0) {
                 switch (a.head_oc) {
-                    case 1: return launch_zpipe<Tag, 5, 8, 16, 2, 4, 1>(a, stream);
-                    case 2: return launch_zpipe<Tag, 5, 8, 16, 2, 4, 2>(a, stream);
-                    case 3: return launch_zpipe<Tag, 5, 8, 16, 2, 4, 3>(a, stream);
-                    case 4: return launch_zpipe<Tag, 5, 8, 16, 2, 4, 4>(a, stream);
+                    case 1: return launch_zpipe<Tag, EXASPIM_HEAD_TZ, 8, 16, 2, 4, 1>(a, stream);
+                    case 2: return launch_zpipe<Tag, EXASPIM_HEAD_TZ, 8, 16, 2, 4, 2>(a, stream);
+                    case 3: return launch_zpipe<Tag, EXASPIM_HEAD_TZ, 8, 16, 2, 4, 3>(a, stream);
+                    case 4: return launch_zpipe<Tag, EXASPIM_HEAD_TZ, 8, 16, 2, 4, 4>(a, stream);
                 }
             }
 #endif
