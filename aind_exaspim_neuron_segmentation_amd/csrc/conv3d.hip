@@ -2378,10 +2378,22 @@ int launch_conv3x3x3(int dtype, const ConvArgs& a_in, hipStream_t stream) {
 
 template <typename Tag>
 static int launch_thin_typed(const ConvArgs& a, hipStream_t stream) {
-    // 2-voxel-thick tiles: thin along y (4 x 2 x 16) or along x (4 x 16 x 2); four waves,
-    // one 32-voxel group each
-    // (four workgroups per CU: a workgroup is four short chunk steps, mostly load latency)
-    if (a.ext[1] <= a.ext[2]) return launch_cfg<Tag, 4, 2, 16, 4, 1, 1, 1, 4, 3, true>(a, stream);
+    // 2-voxel-thick tiles: thin along y (TZ x 2 x 16) or along x (TZ x 16 x 2), four waves. A wave owns
+    // TZ / 4 groups of 32 voxels, so a weight fragment fetched through the L2 ring feeds that many
+    // MFMAs and the z halo is shared by more planes: measured inside 512^3 steps on up4.0's two
+    // remainders (82 planes, rocprofv3, us per launch) thin along y 54.2 / 42.3 - 44.5 / 36.0 for
+    // TZ = 4 / 8 / 12 (three workgroups per CU for 12), thin along x 56.6 / 45.7 / 47.4 - 51.9 (its
+    // 2-voxel rows keep 50 % LDS bank conflicts). The depth is picked per launch: padded planes x
+    // the relative cost per plane from those measurements.
+    const int ez = a.ext[0];
+    auto planes = [&](int tz) { return (ez + tz - 1) / tz * tz; };
+    if (a.ext[1] <= a.ext[2]) {
+        const float c4 = planes(4) * 1.00f, c8 = planes(8) * 0.76f, c12 = planes(12) * 0.66f;
+        if (c12 <= c8 && c12 <= c4) return launch_cfg<Tag, 12, 2, 16, 4, 1, 3, 1, 3, 3, true>(a, stream);
+        if (c8 <= c4) return launch_cfg<Tag, 8, 2, 16, 4, 1, 2, 1, 4, 3, true>(a, stream);
+        return launch_cfg<Tag, 4, 2, 16, 4, 1, 1, 1, 4, 3, true>(a, stream);
+    }
+    if (planes(8) * 0.78f <= planes(4) * 1.00f) return launch_cfg<Tag, 8, 16, 2, 4, 1, 2, 1, 4, 3, true>(a, stream);
     return launch_cfg<Tag, 4, 16, 2, 4, 1, 1, 1, 4, 3, true>(a, stream);
 }
 
