@@ -125,6 +125,68 @@ __global__ __launch_bounds__(256) void histogram_kernel(const void* __restrict__
     }
 }
 
+// 8- and 16-bit integer voxels, pass 0 (the whole job for these dtypes): sixteen bytes per load, the
+// clip as an integer threshold (v > clip <=> v > floor(clip) for an integer v) instead of a double
+// compare per voxel, and the clip's own bin -- where every saturated voxel lands, half of the
+// synthetic volume -- counted with one ballot per wave instead of 64 serialised LDS atomics.
+// `thr`: largest value that is kept (INT_MAX without a clip); `cbin`: bin of a clipped voxel, before `bias`.
+template <typename V>
+__global__ __launch_bounds__(256) void histogram_int_kernel(const V* __restrict__ vol, size_t n, int thr, int cbin,
+                                                            int bias, int window_lo,
+                                                            unsigned long long* __restrict__ hist) {
+    constexpr int PER = 16 / (int)sizeof(V);
+    __shared__ unsigned local[kLdsBins];
+    for (int i = threadIdx.x; i < kLdsBins; i += blockDim.x) local[i] = 0;
+    __syncthreads();
+    unsigned clipped = 0;                         // this lane's share of the wave's clipped voxels
+    auto count = [&](int v, bool live) {
+        const bool sat = live && v > thr;
+        const unsigned long long m = __ballot(sat);
+        if ((threadIdx.x & 63) == 0) clipped += (unsigned)__popcll(m);
+        if (live && !sat) {
+            const int b = v + bias, lb = b - window_lo;
+            if ((unsigned)lb < (unsigned)kLdsBins)
+                atomicAdd(&local[lb], 1u);
+            else
+                atomicAdd(&hist[b], 1ULL);
+        }
+    };
+    const size_t nvec = n / PER;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    // (every lane of a wave runs the same number of iterations: the ballots see whole waves)
+    const size_t rounds = (nvec + stride - 1) / stride;
+    for (size_t r = 0; r < rounds; ++r) {
+        const size_t i = r * stride + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool live = i < nvec;
+        const uint4 q = live ? reinterpret_cast<const uint4*>(vol)[i] : make_uint4(0, 0, 0, 0);
+        const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const unsigned word = w[k * (int)sizeof(V) / 4];
+            const unsigned raw = (word >> (8 * ((k * (int)sizeof(V)) % 4))) & (sizeof(V) == 1 ? 0xffu : 0xffffu);
+            count((int)(V)raw, live);
+        }
+    }
+    // the last n % PER voxels
+    {
+        const size_t t = nvec * PER + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool live = blockIdx.x == 0 && t < n;
+        count(live ? (int)vol[t] : 0, live);
+    }
+    if ((threadIdx.x & 63) == 0 && clipped) {
+        const int b = cbin + bias, lb = b - window_lo;
+        if ((unsigned)lb < (unsigned)kLdsBins)
+            atomicAdd(&local[lb], clipped);
+        else
+            atomicAdd(&hist[b], (unsigned long long)clipped);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kLdsBins; i += blockDim.x) {
+        const unsigned c = local[i];
+        if (c) atomicAdd(&hist[window_lo + i], (unsigned long long)c);
+    }
+}
+
 __global__ __launch_bounds__(256) void histogram_f64_kernel(const void* __restrict__ vol, size_t n, double clip,
                                                             int has_clip, int pass, unsigned long long prefix,
                                                             int window_lo, unsigned long long* __restrict__ hist) {
@@ -390,23 +452,41 @@ __device__ __forceinline__ int axis_count(int g, int dim, int patch, int overlap
     return cnt;
 }
 
-// Grid: x = voxels of one row, y = row, z = plane; the z and y counts are scalar.
+// Grid: x = voxels of one row (VEC per thread), y = row, z = plane; the z and y counts are scalar.
+// VEC = 4 when rows are whole float4s (launcher): a voxel covered once keeps its bits under a
+// division by 1.0f, so a thread divides its four voxels alike and skips the row segment only when
+// none of them is covered more than once.
+template <int VEC>
 __global__ __launch_bounds__(256) void finalize_kernel(float* __restrict__ accum, int channels,
                                                        exaspim_window win, exaspim_block blk) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     if (x >= blk.dims[2]) return;
     const int y = blockIdx.y, z = blockIdx.z;
     const size_t avox = (size_t)blk.dims[0] * blk.dims[1] * blk.dims[2];
     const int cz = axis_count(z + blk.origin[0], blk.global[0], win.patch[0], win.overlap[0], win.trim);
     const int cy = axis_count(y + blk.origin[1], blk.global[1], win.patch[1], win.overlap[1], win.trim);
-    const int cx = axis_count(x + blk.origin[2], blk.global[2], win.patch[2], win.overlap[2], win.trim);
-    const int cnt = cz * cy * cx;
-    if (cnt > 1) {
-        const size_t i = ((size_t)z * blk.dims[1] + y) * blk.dims[2] + x;
+    float wgt[VEC];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        const int cnt = cz * cy * axis_count(x + k + blk.origin[2], blk.global[2], win.patch[2], win.overlap[2], win.trim);
+        any |= cnt > 1;
         // the reference counts in float16 (inference.py:92, accum_wgt += 1): 2048 + 1 rounds
         // back to 2048, so its weights stop there (only strides of a voxel or two get that far)
-        const float wgt = (float)min(cnt, 2048);
-        for (int c = 0; c < channels; ++c) accum[c * avox + i] = __fdiv_rn(accum[c * avox + i], wgt);
+        wgt[k] = (float)max(min(cnt, 2048), 1);
+    }
+    if (!any) return;
+    const size_t i = ((size_t)z * blk.dims[1] + y) * blk.dims[2] + x;
+    for (int c = 0; c < channels; ++c) {
+        float* const p = accum + c * avox + i;
+        if (VEC == 4) {
+            float4 v = *reinterpret_cast<float4*>(p);
+            v.x = __fdiv_rn(v.x, wgt[0]); v.y = __fdiv_rn(v.y, wgt[1]);
+            v.z = __fdiv_rn(v.z, wgt[VEC > 2 ? 2 : 0]); v.w = __fdiv_rn(v.w, wgt[VEC > 3 ? 3 : 0]);
+            *reinterpret_cast<float4*>(p) = v;
+        } else {
+            *p = __fdiv_rn(*p, wgt[0]);
+        }
     }
 }
 
@@ -483,15 +563,27 @@ extern "C" int exaspim_histogram(const void* vol_dev, int32_t vox_dtype, size_t 
                                          ? ((n + 256 * 64 - 1) / (256 * 64) ? (n + 256 * 64 - 1) / (256 * 64) : 1)
                                          : 2048);
     hipStream_t s = (hipStream_t)stream;
+    // integer voxels: the clip as an integer threshold and the bin of a clipped voxel (a fractional clip
+    // gets the bin above its floor); a clip below the dtype has no bin to stand in
+    int thr = 0x7fffffff, cbin = 0;
+    if (vox_dtype != EXASPIM_VOX_F32 && has_clip) {
+        const double lo = vox_dtype == EXASPIM_VOX_I16 ? -32768.0 : 0.0, hi = vox_dtype == EXASPIM_VOX_U8 ? 255.0 : vox_dtype == EXASPIM_VOX_U16 ? 65535.0 : 32767.0;
+        EXA_CHECK_ARG(clip == clip && ceil(clip) >= lo, "histogram: clip %g lies below every voxel of dtype %d", clip, vox_dtype);
+        if (clip < hi) { thr = (int)floor(clip); cbin = (int)ceil(clip); }
+    }
+    const bool vec = ((uintptr_t)vol_dev & 15) == 0;
     switch (vox_dtype) {
         case EXASPIM_VOX_U8:
-            histogram_kernel<EXASPIM_VOX_U8><<<grid, 256, 0, s>>>(vol_dev, n, clip, has_clip, pass, prefix, 0, h);
+            if (vec) histogram_int_kernel<uint8_t><<<grid, 256, 0, s>>>(static_cast<const uint8_t*>(vol_dev), n, thr, cbin, 0, 0, h);
+            else histogram_kernel<EXASPIM_VOX_U8><<<grid, 256, 0, s>>>(vol_dev, n, clip, has_clip, pass, prefix, 0, h);
             break;
         case EXASPIM_VOX_U16:
-            histogram_kernel<EXASPIM_VOX_U16><<<grid, 256, 0, s>>>(vol_dev, n, clip, has_clip, pass, prefix, 0, h);
+            if (vec) histogram_int_kernel<uint16_t><<<grid, 256, 0, s>>>(static_cast<const uint16_t*>(vol_dev), n, thr, cbin, 0, 0, h);
+            else histogram_kernel<EXASPIM_VOX_U16><<<grid, 256, 0, s>>>(vol_dev, n, clip, has_clip, pass, prefix, 0, h);
             break;
         case EXASPIM_VOX_I16:
-            histogram_kernel<EXASPIM_VOX_I16><<<grid, 256, 0, s>>>(vol_dev, n, clip, has_clip, pass, prefix, 32768 - 4096, h);
+            if (vec) histogram_int_kernel<int16_t><<<grid, 256, 0, s>>>(static_cast<const int16_t*>(vol_dev), n, thr, cbin, 32768, 32768 - 4096, h);
+            else histogram_kernel<EXASPIM_VOX_I16><<<grid, 256, 0, s>>>(vol_dev, n, clip, has_clip, pass, prefix, 32768 - 4096, h);
             break;
         case EXASPIM_VOX_F32:
             // non-negative floats up to ~1e5 have key halves 0x8000..0xC7C3
@@ -627,8 +719,13 @@ extern "C" int exaspim_stitch_finalize(float* accum_dev, int32_t channels,
     if (int rc = check_window(win, "finalize")) return rc;
     EXA_CHECK_ARG(accum_dev && channels >= 1, "finalize: bad arguments");
     EXA_CHECK_ARG(blk->dims[0] <= 65535 && blk->dims[1] <= 65535, "finalize: block too large");
-    const dim3 grid((blk->dims[2] + 255) / 256, blk->dims[1], blk->dims[0]);
-    finalize_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(accum_dev, channels, *win, *blk);
+    if (blk->dims[2] % 4 == 0 && ((uintptr_t)accum_dev & 15) == 0) {
+        const dim3 grid((blk->dims[2] / 4 + 255) / 256, blk->dims[1], blk->dims[0]);
+        finalize_kernel<4><<<grid, 256, 0, (hipStream_t)stream>>>(accum_dev, channels, *win, *blk);
+    } else {
+        const dim3 grid((blk->dims[2] + 255) / 256, blk->dims[1], blk->dims[0]);
+        finalize_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(accum_dev, channels, *win, *blk);
+    }
     EXA_CHECK_HIP(hipGetLastError());
     return EXASPIM_OK;
 }

@@ -574,6 +574,8 @@ def _effective_clip(np_dtype, brightness_clip, storage_dtype=None):
             f"brightness_clip {brightness_clip!r} promotes {np_dtype} voxels to {probe.dtype}"
         )
     clip = np.float64(brightness_clip)
+    if np_dtype.kind in "iu" and clip < np.iinfo(np_dtype).min:
+        raise NotImplementedError(f"brightness_clip {brightness_clip!r} lies below every {np_dtype} voxel")
     storage = np.dtype(storage_dtype) if storage_dtype is not None else _device_voxel_dtype(np_dtype)[0]
     if storage == np.float32 and np_dtype != np.float32 and np.float64(np.float32(clip)) != clip:
         # (predict() sends such a volume as float64 instead: _device_voxel_dtype(..., clip=))

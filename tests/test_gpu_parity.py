@@ -682,6 +682,17 @@ def test_predict_rejects_what_no_float_can_carry(dev):
         inference.predict(vol.astype(np.complex64), model, **kw)
     with pytest.raises(OverflowError):          # numpy's own refusal (inference.py:79)
         inference.predict((vol % 251).astype(np.uint8), model, brightness_clip=1000, **kw)
+    # a clip below every voxel an unsigned image can hold has no histogram bin to stand in: refused in
+    # Python, and again at the C ABI (which must never index a bin below zero)
+    with pytest.raises(NotImplementedError, match="below every"):
+        inference.predict(vol, model, brightness_clip=-3.5, **kw)
+    from aind_exaspim_neuron_segmentation_amd import _native
+    t = torch.from_numpy(vol.view(np.int16)).to(dev)
+    hist = torch.zeros(65536, dtype=torch.int64, device=dev)
+    rc = _native.lib().exaspim_histogram(t.data_ptr(), _native.VOX_U16, t.numel(), -3.5, 1, 0, 0, hist.data_ptr(), None)
+    assert rc == -1 and "below every voxel" in _native.last_error()
+    torch.cuda.synchronize()
+    assert int(hist.sum()) == 0
 
 
 @pytest.mark.parametrize("switch", ["EXASPIM_ZPAIR", "EXASPIM_T16"])

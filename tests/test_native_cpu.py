@@ -348,6 +348,9 @@ def test_dtype_rules_and_fractional_clip_percentiles_on_the_host():
     assert inf._effective_clip(np.uint8, np.int16(255)) == (None, np.dtype(np.int16))
     with pytest.raises(NotImplementedError):      # everything would become the clip
         inf._effective_clip(np.uint16, np.int32(-5))
+    with pytest.raises(NotImplementedError):      # (a fractional one too: no bin stands for it)
+        inf._effective_clip(np.uint16, -3.5)
+    assert inf._effective_clip(np.int16, -3.5) == (np.float64(-3.5), np.dtype(np.float64))
     with pytest.raises(NotImplementedError):      # float32 arithmetic in np.percentile and normalize
         inf._effective_clip(np.uint16, np.float32(5))
     # an int16 image whose order statistics lie more than 32767 apart: numpy's own int16 lerp wraps,
