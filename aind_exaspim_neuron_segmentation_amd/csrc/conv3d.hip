@@ -779,6 +779,9 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
     constexpr int LDS_UNITS = XUNITS + WUNITS;
     constexpr int NS = 9 * HZ;             // steps per chunk
     constexpr int R = D + 1;               // operand ring
+#ifndef EXASPIM_POOL_DIRECT
+#define EXASPIM_POOL_DIRECT 1   // z-column kernel, 16-bit, fused max-pool: output from registers, pair maxima through LDS (0: all planes through LDS)
+#endif
 #ifndef EXASPIM_HEAD_TZ
 #define EXASPIM_HEAD_TZ 5   // planes per tile of the trimmed fused-head launch (0: the 6-plane tiles of every other launch; A/B builds)
 #endif
@@ -1181,6 +1184,81 @@ __global__ __launch_bounds__(TY* TX * 2, MINW) void conv3x3x3_zpipe(
 #endif
                 }
             }
+        } else if (ES == 2 && POOL && EXASPIM_POOL_DIRECT) {
+            // ---- epilogue with the fused max-pool, 16-bit types: the layer's own output leaves the
+            // registers like in the branch above (v_permlane32_swap, no LDS); of a PAIR of planes only the
+            // element-wise maximum goes to LDS, as order-preserving keys, and a pooled piece is the maximum
+            // over the 2 x 2 records of its row pair there. Against parking all six planes: half the LDS
+            // writes, a third of the reads, no read-back for the 12 output stores. Maximum of the stored
+            // (rounded, saturated) values like maxpool2_kernel: same bits.
+            static_assert(!(ES == 2 && POOL) || (TZ % 2 == 0 && TY % 2 == 0 && TX == 16), "pooled tile shape");
+            constexpr int CPT = 2;
+            char* wl = reinterpret_cast<char*>(lds) + wave * ((TZ / 2) * 32 * RECP);
+            char* const dplane = static_cast<char*>(a.dst) +
+                                 ((size_t)cur.nb * (a.cout / KC) + ntile0 * 2) * patch_vox * 32;
+            const int gy = cur.y0 + pos_e / TX, gx = cur.x0 + pos_e % TX;
+            const bool okyx = gy < a.org[1] + a.ext[1] && gx < a.org[2] + a.ext[2];
+            const unsigned ovoff = okyx ? (unsigned)(gy * a.w + gx) * 32u + half_e * 16u : kOutOfRange;
+#pragma unroll
+            for (int zp = 0; zp < TZ / 2; ++zp) {
+                uint2 grp[2][4];
+#pragma unroll
+                for (int zz = 0; zz < 2; ++zz)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        grp[zz][q] = pack4<Tag>(leaky(acc[2 * zp + zz][4 * q + 0], a.slope), leaky(acc[2 * zp + zz][4 * q + 1], a.slope),
+                                                leaky(acc[2 * zp + zz][4 * q + 2], a.slope), leaky(acc[2 * zp + zz][4 * q + 3], a.slope));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {      // the pair's maximum, as keys, where the pooling pass finds it
+                    const uint2 km = make_uint2(maxkey16x2(key16x2(grp[0][q].x), key16x2(grp[1][q].x)),
+                                                maxkey16x2(key16x2(grp[0][q].y), key16x2(grp[1][q].y)));
+                    *reinterpret_cast<uint2*>(wl + zp * (32 * RECP) + r_e * RECP + (8 * q + 4 * half_e) * ES) = km;
+                }
+#pragma unroll
+                for (int zz = 0; zz < 2; ++zz) {
+                    const int gz = cur.z0 + 2 * zp + zz;     // wave-uniform
+                    const __amdgpu_buffer_rsrc_t orsrc =
+                        make_rsrc(dplane, gz < a.org[0] + a.ext[0] ? (size_t)2 * patch_vox * 32 : (size_t)0);
+#pragma unroll
+                    for (int ck = 0; ck < 2; ++ck) {
+                        const uint4 rec = record_half(grp[zz][2 * ck], grp[zz][2 * ck + 1]);
+                        buf_store16(rec, orsrc, ovoff, ((unsigned)ck * (unsigned)patch_vox + (unsigned)gz * (unsigned)plane_vox) * 32u);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            {
+                // the wave's 2 rows x 16 voxels x TZ / 2 plane pairs give TZ / 2 x 8 pooled voxels; a piece is
+                // one 16-byte group of one of them (record = row * 16 + x)
+                constexpr int NP = (TZ / 2) * 8 * CPT * 2;
+                const int pd = a.d >> 1, ph = a.h >> 1, pw2 = a.w >> 1;
+                const size_t pvox = (size_t)pd * ph * pw2;
+                char* const pplane = static_cast<char*>(a.pool_dst) +
+                                     ((size_t)cur.nb * (a.cout / KC) + ntile0 * CPT) * pvox * 32;
+                const __amdgpu_buffer_rsrc_t prsrc = make_rsrc(pplane, (size_t)CPT * pvox * 32);
+#pragma unroll
+                for (int p0 = 0; p0 < NP; p0 += 64) {
+                    const int p = p0 + lane_e;
+                    const bool live = p < NP;        // (a lane without a piece works on piece 0; its store is dropped)
+                    const int pc = live ? p : 0;
+                    const int zp = pc / (8 * CPT * 2), rem = pc % (8 * CPT * 2);
+                    const int ck = rem / 16, xp = (rem % 16) >> 1, sb = rem & 1;
+                    const char* rec = wl + zp * (32 * RECP) + (2 * xp) * RECP + (ck * 2 + sb) * 16;
+                    uint4 m = *reinterpret_cast<const uint4*>(rec);
+#pragma unroll
+                    for (int k = 1; k < 4; ++k)
+                        m = maxkey16(m, *reinterpret_cast<const uint4*>(rec + (k >> 1) * 16 * RECP + (k & 1) * RECP));
+                    m = key16(m);
+                    const int qz = cur.z0 / 2 + zp, qy = cur.y0 / 2 + wave, qx = cur.x0 / 2 + xp;
+                    const unsigned pvoff = live && qz < pd && qy < ph && qx < pw2
+                                               ? (unsigned)((ck * (int)pvox + (qz * ph + qy) * pw2 + qx) * 32 + sb * 16)
+                                               : kOutOfRange;
+                    buf_store16(m, prsrc, pvoff, 0u);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         } else {
             // ---- epilogue: LeakyReLU, transposed through LDS ----------------------
             // One store instruction writes one chunk plane's 32 voxel records (32 B
