@@ -484,6 +484,114 @@ __device__ __forceinline__ int axis_count(int g, int dim, int patch, int overlap
     return cnt;
 }
 
+// The same overlap-add with four x-neighbours per thread (r03): 16-byte loads and stores of the patch
+// outputs and of the accumulator instead of 4-byte ones. Four neighbours share their set of covering
+// patches whenever every box edge along x falls on a multiple of four relative to the accumulator --
+// starts that agree mod 4, a trim and row lengths that are multiples of 4 (the default geometry: starts
+// are multiples of 64, trim 8) -- which a block checks for the patches near its own with one ballot;
+// otherwise its threads walk their four voxels one by one through the same code (V = 1). Ownership and
+// the order of the additions are the scalar kernel's: same bits.
+template <int C, int V>
+__device__ __forceinline__ void stitch_voxels(const float* __restrict__ pred, const int* __restrict__ starts,
+                                              const exaspim_window& win, float* __restrict__ accum,
+                                              const exaspim_block& blk, int p, unsigned long long near,
+                                              int z, int y, int x, size_t pvox, size_t avox) {
+    const int* sp = starts + 3 * p;
+    const int gz = sp[0] + win.trim + z, gy = sp[1] + win.trim + y, gx = sp[2] + win.trim + x;
+    if (gz >= blk.global[0] || gy >= blk.global[1] || gx >= blk.global[2]) return;
+    const int lz = gz - blk.origin[0], ly = gy - blk.origin[1], lx = gx - blk.origin[2];
+    if ((unsigned)lz >= (unsigned)blk.dims[0] || (unsigned)ly >= (unsigned)blk.dims[1] ||
+        (unsigned)lx >= (unsigned)blk.dims[2])
+        return;
+    const size_t a = ((size_t)lz * blk.dims[1] + ly) * blk.dims[2] + lx;
+    unsigned long long before = near & ((1ULL << p) - 1ULL);
+    while (before) {
+        const int j = __ffsll((long long)before) - 1;
+        before &= before - 1ULL;
+        if (covered(starts + 3 * j, win, blk.global, gz, gy, gx)) return;
+    }
+    float s[C][V];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        if (V == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(accum + c * avox + a);
+            s[c][0] = t.x; s[c][V > 1 ? 1 : 0] = t.y; s[c][V > 2 ? 2 : 0] = t.z; s[c][V > 3 ? 3 : 0] = t.w;
+        } else {
+            s[c][0] = accum[c * avox + a];
+        }
+    }
+    unsigned long long rest = near & ~((1ULL << p) - 1ULL);  // p itself and later neighbours
+    while (rest) {
+        const int j = __ffsll((long long)rest) - 1;
+        rest &= rest - 1ULL;
+        const int* sj = starts + 3 * j;
+        if (j != p && !covered(sj, win, blk.global, gz, gy, gx)) continue;
+        const size_t o = ((size_t)(gz - sj[0]) * win.patch[1] + (gy - sj[1])) * win.patch[2] + (gx - sj[2]);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float* q = pred + ((size_t)j * C + c) * pvox + o;
+            if (V == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(q);
+                s[c][0] += t.x; s[c][V > 1 ? 1 : 0] += t.y; s[c][V > 2 ? 2 : 0] += t.z; s[c][V > 3 ? 3 : 0] += t.w;
+            } else {
+                s[c][0] += q[0];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        if (V == 4)
+            *reinterpret_cast<float4*>(accum + c * avox + a) =
+                make_float4(s[c][0], s[c][V > 1 ? 1 : 0], s[c][V > 2 ? 2 : 0], s[c][V > 3 ? 3 : 0]);
+        else
+            accum[c * avox + a] = s[c][0];
+    }
+}
+
+// Grid: x = blocks of 4-voxel groups of one trimmed output plane, y = patch * trimmed depth (n <= 64,
+// trimmed row length a multiple of 4: the launcher sends everything else to stitch_kernel).
+template <int C>
+__global__ __launch_bounds__(256) void stitch4_kernel(const float* __restrict__ pred,
+                                                      const int* __restrict__ starts, int n,
+                                                      exaspim_window win, float* __restrict__ accum,
+                                                      exaspim_block blk) {
+    const int oz = win.patch[0] - 2 * win.trim, oy = win.patch[1] - 2 * win.trim,
+              ox = win.patch[2] - 2 * win.trim;
+    const size_t pvox = (size_t)win.patch[0] * win.patch[1] * win.patch[2];
+    const size_t avox = (size_t)blk.dims[0] * blk.dims[1] * blk.dims[2];
+    const int gpr = ox >> 2;                                  // groups per row
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // group inside the trimmed plane
+    const int y = i / gpr, x = (i - y * gpr) * 4;
+    const int p = blockIdx.y / oz, z = blockIdx.y - p * oz;
+    const int* sp = starts + 3 * p;
+    __shared__ unsigned long long near_mask, odd_mask;
+    if (threadIdx.x < 64) {
+        const int j = threadIdx.x;
+        bool hit = false, odd = false;
+        if (j < n) {
+            const int* sj = starts + 3 * j;
+            const int dz = sj[0] - sp[0], dy = sj[1] - sp[1], dx = sj[2] - sp[2];
+            hit = dz > -oz && dz < oz && dy > -oy && dy < oy && dx > -ox && dx < ox;
+            odd = hit && (dx & 3) != 0;
+        }
+        const unsigned long long m = __ballot(hit), mo = __ballot(odd);
+        if (threadIdx.x == 0) { near_mask = m; odd_mask = mo; }
+    }
+    __syncthreads();
+    if (y >= oy) return;
+    const unsigned long long near = near_mask;
+    // every x edge of the near boxes on a multiple of four of the accumulator's rows, 16-byte aligned bases
+    const bool fast = odd_mask == 0 && (win.trim & 3) == 0 && (blk.dims[2] & 3) == 0 && ((blk.global[2] - sp[2] - win.trim) & 3) == 0 &&
+                      ((sp[2] + win.trim - blk.origin[2]) & 3) == 0 && (win.patch[2] & 3) == 0 &&
+                      (((uintptr_t)pred | (uintptr_t)accum) & 15) == 0;
+    if (fast) {
+        stitch_voxels<C, 4>(pred, starts, win, accum, blk, p, near, z, y, x, pvox, avox);
+    } else {
+        for (int v = 0; v < 4; ++v)
+            stitch_voxels<C, 1>(pred, starts, win, accum, blk, p, near, z, y, x + v, pvox, avox);
+    }
+}
+
 // Grid: x = voxels of one row (VEC per thread), y = row, z = plane; the z and y counts are scalar.
 // VEC = 4 when rows are whole float4s (launcher): a voxel covered once keeps its bits under a
 // division by 1.0f, so a thread divides its four voxels alike and skips the row segment only when
@@ -734,6 +842,17 @@ extern "C" int exaspim_stitch_accumulate(const float* pred_dev, const int32_t* s
     EXA_CHECK_ARG((long long)n * oz <= 65535 && (long long)oy * ox < 0x7fffffffLL, "stitch: grid too large");
     const dim3 grid((unsigned)(((long long)oy * ox + 255) / 256), n * oz);
     hipStream_t s = (hipStream_t)stream;
+    if (n <= 64 && ox % 4 == 0) {       // four x-neighbours per thread (falls back per block where they differ)
+        const dim3 grid4((unsigned)(((long long)oy * (ox / 4) + 255) / 256), n * oz);
+        switch (channels) {
+            case 1: stitch4_kernel<1><<<grid4, 256, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
+            case 2: stitch4_kernel<2><<<grid4, 256, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
+            case 3: stitch4_kernel<3><<<grid4, 256, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
+            case 4: stitch4_kernel<4><<<grid4, 256, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
+        }
+        EXA_CHECK_HIP(hipGetLastError());
+        return EXASPIM_OK;
+    }
     switch (channels) {
         case 1: stitch_kernel<1><<<grid, 256, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
         case 2: stitch_kernel<2><<<grid, 256, 0, s>>>(pred_dev, starts_dev, n, *win, accum_dev, *blk); break;
