@@ -284,6 +284,7 @@ def dominant_roofline(ms, cnt, dtype, batch, patches_per_step):
     launches = sum(cnt[b] for b, _, _, _ in DOMINANT_CONVS)
     k_ms = sum(ms[b] for b, _, _, _ in DOMINANT_CONVS)
     flops = 0.0
+    issued = 0.0    # what the launches' whole 6 x 8 x 16 tiles compute (masked planes included)
     for b, cin, cout, edge in DOMINANT_CONVS:
         # up4.0 (bit 15) only computes what up4.3 reads of the voxels predict() keeps:
         # trim - 1 voxels less on every face (exaspim_unet_forward_trimmed) = 82^3; of
@@ -292,9 +293,13 @@ def dominant_roofline(ms, cnt, dtype, batch, patches_per_step):
         need = edge - 2 * (TRIM - 1) if b == 15 else edge
         vox = need * zcol_main(need, 8) * zcol_main(need, 16) if b == 15 else need ** 3
         flops += cnt[b] * 2.0 * 27 * cin * cout * batch * vox
+        tiles = (-(-need // 6)) * (-(-(zcol_main(need, 8) if b == 15 else need) // 8)) * \
+                (-(-(zcol_main(need, 16) if b == 15 else need) // 16))
+        issued += cnt[b] * 2.0 * 27 * cin * cout * batch * tiles * (6 * 8 * 16)
     # the last batch of a step may be short; scale by the real patch count
     full_batches = -(-patches_per_step // batch)
     flops *= patches_per_step / float(full_batches * batch)
+    issued *= patches_per_step / float(full_batches * batch)
     achieved = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
     peak = PEAK_TFLOPS[dtype]
     launches_per_step = len(DOMINANT_CONVS) * full_batches
@@ -313,6 +318,7 @@ def dominant_roofline(ms, cnt, dtype, batch, patches_per_step):
         "bound": "mfma",
         "kernel": f"conv3x3x3_zpipe<{tag}, tile 6x8x16, 32 couts, no head, no pool> (launches: up3.3, up4.0)",
         "algorithmic_flop_per_launch": flops / launches if launches else None,
+        "issued_flop_per_launch": issued / launches if launches else None,
         "achieved": achieved,
         "peak": peak,
         "unit": "TFLOP/s",
