@@ -763,7 +763,9 @@ static int gather_launch(const void* vol_dev, int32_t vox_dtype, const exaspim_b
     constexpr int B = LAYOUT == EXASPIM_IN_F32 ? 0 : 1;
     EXA_CHECK_ARG((long long)n * (patch[0] + 2 * B) <= 65535 && patch[1] + 2 * B <= 65535, "gather: grid too large");
     // table path: unsigned integers clipped to a small integer maximum
+    // (table + row map within the 64 KiB a launch gets without asking for more)
     if (has_clip && clip >= 0.0 && clip <= 16383.0 && clip == (double)(int)clip &&
+        ((size_t)clip + 1) * sizeof(float) + (size_t)(patch[1] + 2 * B) * sizeof(int) <= 65536 &&
         (vox_dtype == EXASPIM_VOX_U8 || vox_dtype == EXASPIM_VOX_U16)) {
         const int ci = (int)clip;
         const size_t lds = ((size_t)ci + 1) * sizeof(float) + (size_t)(patch[1] + 2 * B) * sizeof(int);   // table + row map

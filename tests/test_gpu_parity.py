@@ -843,6 +843,31 @@ def _split_words(x, kind):
     return hi | (lo << 16)
 
 
+@pytest.mark.parametrize("clip", [16383, 16300, 16384, 40000])
+def test_gather_table_path_at_its_largest_clips(dev, oracle, clip):
+    """The table of the unsigned-integer gather (one normalised value per voxel value up to the clip) and
+    its row map share the 64 KiB of dynamic LDS a launch gets: clips near 16 383 take the generic path once
+    the two no longer fit -- plain and zero-bordered split layouts, bit for bit against the oracle."""
+    from aind_exaspim_neuron_segmentation_amd import _native, inference
+
+    arr = (synthetic.synth_volume((40, 48, 56), seed=11).astype(np.uint32) * 23 % 50000).astype(np.uint16)
+    patch, overlap = (32, 32, 48), (8, 4, 40)
+    clipped = np.minimum(arr, clip)
+    mn, mx = np.percentile(clipped, (1, 99.9))
+    img = oracle.normalize(clipped)[None, None]
+    starts = list(oracle.generate_patch_starts(img.shape, patch, overlap))
+    want = oracle.get_batch_inputs(img, starts, patch).numpy()
+    vol = inference.DeviceVolume.from_array(arr, dev)
+    sdev = torch.tensor(starts, dtype=torch.int32, device=dev)
+    got = inference._get_batch_inputs(vol, sdev, patch, dev, clip=np.uint16(clip), mn=mn, mx=mx)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    padded = inference._get_batch_inputs(vol, sdev, patch, dev, clip=np.uint16(clip), mn=mn, mx=mx,
+                                         layout=_native.IN_PADDED_F32).cpu().numpy()
+    padded = padded.reshape((len(starts),) + tuple(p + 2 for p in patch))
+    np.testing.assert_array_equal(padded[:, 1:-1, 1:-1, 1:-1], want[:, 0])
+    assert not padded[:, 0].any() and not padded[:, :, -1].any() and not padded[..., 0].any()
+
+
 @pytest.mark.parametrize("vox,clip", [(np.uint16, 1000), (np.float32, None), (np.int16, 700.5), (np.uint8, 200)])
 def test_gather_writes_the_first_convolutions_operand_layout(dev, vox, clip):
     """exaspim_gather_patches_as: the zero-bordered float32 copy and the hi | lo << 16 split
