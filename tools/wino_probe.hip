@@ -34,6 +34,9 @@ __device__ __forceinline__ f32x16 mma(const f32x16& acc, const uint4& a, const u
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
 }
 
+#ifndef DIRECT_ORDER
+#define DIRECT_ORDER 2
+#endif
 constexpr int kSlots = 4096;   // 64 KiB of LDS per workgroup
 
 __global__ __launch_bounds__(256, 2) void direct(const uint4* __restrict__ src, float* out, int iters) {
@@ -49,10 +52,24 @@ __global__ __launch_bounds__(256, 2) void direct(const uint4* __restrict__ src, 
         for (int k = 0; k < 8; ++k) d[k] = lds[(base + k * 64) & (kSlots - 1)];
 #pragma unroll
         for (int k = 0; k < 3; ++k) w[k] = lds[(base + (8 + k) * 64) & (kSlots - 1)];
+#if DIRECT_ORDER == 1      // weight-stationary: one weight fragment for six consecutive MFMAs
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+            for (int z = 0; z < 6; ++z) acc[z] = mma(acc[z], w[dz], d[z + dz]);
+#elif DIRECT_ORDER == 2    // operand-stationary: one input plane for up to three consecutive MFMAs (the kernel's order)
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz)
+                if (k - dz >= 0 && k - dz < 6) acc[k - dz] = mma(acc[k - dz], w[dz], d[k]);
+#else                      // accumulator-stationary
 #pragma unroll
         for (int z = 0; z < 6; ++z)
 #pragma unroll
             for (int dz = 0; dz < 3; ++dz) acc[z] = mma(acc[z], w[dz], d[z + dz]);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
     }
     float s = 0;
     for (int k = 0; k < 6; ++k) for (int j = 0; j < 16; ++j) s += acc[k][j];
